@@ -1,0 +1,62 @@
+"""Generate the committed golden fixtures.  Run in the AUTHORING container only:
+
+    python tests/golden/make_golden.py
+
+It imports the one runnable fragment of the reference,
+/root/reference/geometry/mesh_utils.py::compute_G_matrix (:38-69), by file
+path (its package __init__ pulls pypgo, which is not installed), and reads the
+reference's only real tet mesh, /root/reference/tssplat_ext/a.veg.  Neither
+exists on the GPU box, hence the outputs are committed:
+
+* g_matrix_golden.npz -- per-tet 9x12 gradient operators from the REFERENCE
+  function on (a) 192 tets of a.veg (with the vertices they touch, float32
+  positions promoted to float64 exactly as tet_spheres.cpp:252-255 does) and
+  (b) a full kuhn_ball(2).  Pins the oracle's `G` (oracle/tet_energy_oracle.py).
+* aveg_mesh.npz -- a.veg converted to the extension's input layout
+  (float32 [n,3], int32 [m,4], 0-based): the "real TetWild-quality mesh"
+  fixture of SURVEY.md 8(d).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+from tssplat_amd import scenes  # noqa: E402
+
+REF = "/root/reference"
+
+
+def main():
+    spec = importlib.util.spec_from_file_location("ref_mesh_utils", f"{REF}/geometry/mesh_utils.py")
+    mu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mu)
+
+    v, t = scenes.read_veg(f"{REF}/tssplat_ext/a.veg")
+    v32 = v.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "aveg_mesh.npz"), rest=v32, tets=t.astype(np.int32))
+
+    rng = np.random.default_rng(7)
+    pick = np.sort(rng.choice(t.shape[0], size=192, replace=False))
+    sub_t = t[pick]
+    used, inv = np.unique(sub_t, return_inverse=True)
+    sub_v = v32[used]
+    sub_t = inv.reshape(-1, 4).astype(np.int32)
+    G_a = mu.compute_G_matrix(sub_v.astype(np.float64), sub_t.astype(np.int64))
+
+    kv, kt = scenes.kuhn_ball(2)
+    kv32 = kv.astype(np.float32)
+    G_k = mu.compute_G_matrix(kv32.astype(np.float64), kt.astype(np.int64))
+
+    np.savez_compressed(
+        os.path.join(HERE, "g_matrix_golden.npz"),
+        aveg_rest=sub_v, aveg_tets=sub_t, aveg_tet_ids=pick.astype(np.int32), aveg_G=G_a,
+        kuhn2_rest=kv32, kuhn2_tets=kt.astype(np.int32), kuhn2_G=G_k,
+    )
+    print("wrote", os.listdir(HERE))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,261 @@
+"""Synthetic tet-sphere scenes and tet-mesh file I/O.
+
+Pure numpy, no GPU.  These generators define the workloads that SURVEY.md
+section 8(d) names; `bench.py`, the tests and the oracle all draw from here so
+that every leg sees bit-identical inputs for a given seed.
+
+Layout contract (mirrors the reference's multi-sphere concatenation,
+/root/reference/geometry/tetmesh_geometry.py:310-331): spheres are stacked
+one after another, sphere ``s`` owns a contiguous vertex range, tet indices
+are offset by the running vertex count, positions are float32 ``[n, 3]`` and
+tets are int32 ``[m, 4]`` with 0-based indices.
+"""
+from __future__ import annotations
+
+import itertools
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+__all__ = [
+    "TetScene",
+    "kuhn_ball",
+    "cone_sphere",
+    "icosphere_surface",
+    "replicate_spheres",
+    "make_scene",
+    "deform",
+    "read_veg",
+    "write_veg",
+]
+
+
+@dataclass
+class TetScene:
+    """A batch of tet-spheres in the reference's flat layout."""
+
+    rest: np.ndarray            # float32 [n, 3] rest positions
+    tets: np.ndarray            # int32   [m, 4]
+    sphere_vertex_offsets: np.ndarray  # int64 [S+1]
+    sphere_tet_offsets: np.ndarray     # int64 [S+1]
+    radii: np.ndarray           # float64 [S] scale applied to each sphere
+
+    @property
+    def n_vertices(self) -> int:
+        return int(self.rest.shape[0])
+
+    @property
+    def n_tets(self) -> int:
+        return int(self.tets.shape[0])
+
+    @property
+    def n_spheres(self) -> int:
+        return int(self.radii.shape[0])
+
+
+def _orient_positive(verts: np.ndarray, tets: np.ndarray) -> np.ndarray:
+    """Swap local vertices 1<->2 of negatively oriented tets so det(Dm) > 0."""
+    p = verts[tets].astype(np.float64)
+    dm = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]], axis=2)
+    neg = np.linalg.det(dm) < 0
+    out = tets.copy()
+    out[neg, 1], out[neg, 2] = tets[neg, 2], tets[neg, 1]
+    return out
+
+
+def kuhn_ball(k: int, blend: float = 0.5) -> tuple[np.ndarray, np.ndarray]:
+    """Rounded-cube tet-sphere: (k+1)^3 lattice, 6 Kuhn tets per cell.
+
+    SURVEY.md 8(d): vertex id ``(i*(k+1)+j)*(k+1)+l`` on [-1,1]^3; every cube
+    is cut into the 6 Freudenthal simplices (one per axis permutation); the
+    lattice is then pushed towards the unit ball with
+    ``p <- p * ((1-blend) + blend * |p|_inf / |p|_2)``.
+    Returns float64 ``[n,3]`` vertices and int32 ``[m,4]`` positively oriented
+    tets.  k=8 -> n=729, m=3072; k=19 -> n=8000, m=41154.
+    """
+    if k < 1:
+        raise ValueError("k must be >= 1")
+    g = np.linspace(-1.0, 1.0, k + 1)
+    ii, jj, ll = np.meshgrid(g, g, g, indexing="ij")
+    verts = np.stack([ii.ravel(), jj.ravel(), ll.ravel()], axis=1)
+    n2 = np.linalg.norm(verts, axis=1)
+    ninf = np.abs(verts).max(axis=1)
+    scale = np.where(n2 > 0, (1.0 - blend) + blend * ninf / np.maximum(n2, 1e-300), 1.0)
+    verts = verts * scale[:, None]
+
+    def vid(i, j, l):
+        return (i * (k + 1) + j) * (k + 1) + l
+
+    ci, cj, cl = np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij")
+    ci, cj, cl = ci.ravel(), cj.ravel(), cl.ravel()
+    tets = []
+    for perm in itertools.permutations(range(3)):
+        cur = [ci.copy(), cj.copy(), cl.copy()]
+        corners = [vid(*cur)]
+        for ax in perm:
+            cur[ax] = cur[ax] + 1
+            corners.append(vid(*cur))
+        tets.append(np.stack(corners, axis=1))
+    # interleave so the 6 tets of a cell are adjacent in memory
+    tets = np.stack(tets, axis=1).reshape(-1, 4).astype(np.int32)
+    tets = _orient_positive(verts, tets)
+    return verts, tets
+
+
+def icosphere_surface(subdiv: int = 3) -> tuple[np.ndarray, np.ndarray]:
+    """Unit icosphere surface (float64 verts, int32 outward triangles)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = np.array(
+        [[-1, t, 0], [1, t, 0], [-1, -t, 0], [1, -t, 0], [0, -1, t], [0, 1, t],
+         [0, -1, -t], [0, 1, -t], [t, 0, -1], [t, 0, 1], [-t, 0, -1], [-t, 0, 1]],
+        dtype=np.float64)
+    f = np.array(
+        [[0, 11, 5], [0, 5, 1], [0, 1, 7], [0, 7, 10], [0, 10, 11], [1, 5, 9],
+         [5, 11, 4], [11, 10, 2], [10, 7, 6], [7, 1, 8], [3, 9, 4], [3, 4, 2],
+         [3, 2, 6], [3, 6, 8], [3, 8, 9], [4, 9, 5], [2, 4, 11], [6, 2, 10],
+         [8, 6, 7], [9, 8, 1]], dtype=np.int64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for _ in range(subdiv):
+        cache: dict[tuple[int, int], int] = {}
+        vl = list(v)
+        nf = []
+
+        def mid(a, b):
+            key = (a, b) if a < b else (b, a)
+            if key not in cache:
+                p = vl[a] + vl[b]
+                vl.append(p / np.linalg.norm(p))
+                cache[key] = len(vl) - 1
+            return cache[key]
+
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [[a, ab, ca], [b, bc, ab], [c, ca, bc], [ab, bc, ca]]
+        v = np.array(vl)
+        f = np.array(nf, dtype=np.int64)
+    return v, f.astype(np.int32)
+
+
+def cone_sphere(surface_v: np.ndarray, surface_f: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """Cone every surface triangle to the centroid: one hub vertex of huge valence.
+
+    The contention stress fixture of SURVEY.md 8(d) (``s1_cone`` when fed the
+    reference's template sphere, an icosphere otherwise).
+    """
+    c = surface_v.mean(axis=0, keepdims=True)
+    verts = np.concatenate([surface_v, c], axis=0)
+    hub = surface_v.shape[0]
+    tets = np.concatenate(
+        [np.full((surface_f.shape[0], 1), hub, dtype=np.int32), surface_f.astype(np.int32)], axis=1)
+    tets = _orient_positive(verts, tets)
+    return verts, tets
+
+
+def replicate_spheres(verts: np.ndarray, tets: np.ndarray, n_spheres: int,
+                      seed: int = 0) -> TetScene:
+    """Stack ``n_spheres`` scaled/translated copies of one template tet mesh.
+
+    Sphere ``s``: radius ``r_s ~ U(0.05, 0.30)``, centre ``c_s ~ U(-0.7, 0.7)^3``
+    from ``numpy.random.default_rng(seed)``.
+    """
+    rng = np.random.default_rng(seed)
+    radii = rng.uniform(0.05, 0.30, size=n_spheres)
+    centres = rng.uniform(-0.7, 0.7, size=(n_spheres, 3))
+    nv, nt = verts.shape[0], tets.shape[0]
+    rest = np.empty((n_spheres * nv, 3), dtype=np.float32)
+    allt = np.empty((n_spheres * nt, 4), dtype=np.int32)
+    v32 = verts.astype(np.float64)
+    for s in range(n_spheres):
+        rest[s * nv:(s + 1) * nv] = (v32 * radii[s] + centres[s]).astype(np.float32)
+        allt[s * nt:(s + 1) * nt] = tets + np.int32(s * nv)
+    return TetScene(
+        rest=rest,
+        tets=allt,
+        sphere_vertex_offsets=np.arange(n_spheres + 1, dtype=np.int64) * nv,
+        sphere_tet_offsets=np.arange(n_spheres + 1, dtype=np.int64) * nt,
+        radii=radii,
+    )
+
+
+def make_scene(kind: str, n_spheres: int, seed: int = 0) -> TetScene:
+    """Named workloads: ``kuhn8`` (3 072 tets/sphere), ``kuhn19`` (41 154),
+    ``kuhnK`` for any K, ``cone`` (icosphere coned to its centre)."""
+    if kind.startswith("kuhn"):
+        v, t = kuhn_ball(int(kind[4:]))
+    elif kind == "cone":
+        v, t = cone_sphere(*icosphere_surface(3))
+    else:
+        raise ValueError(f"unknown scene kind {kind!r}")
+    return replicate_spheres(v, t, n_spheres, seed=seed)
+
+
+def deform(scene: TetScene, sigma: float, seed: int = 1) -> np.ndarray:
+    """``x = X_rest + sigma * r_s * N(0,1)`` in float32."""
+    rng = np.random.default_rng(seed)
+    noise = rng.standard_normal(scene.rest.shape)
+    per_vertex_r = np.repeat(scene.radii, np.diff(scene.sphere_vertex_offsets))
+    return (scene.rest.astype(np.float64) + sigma * per_vertex_r[:, None] * noise).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- #
+# Vega .veg tet meshes (the format behind TetSpheres(filename),
+# /root/reference/tssplat_ext/tet_spheres/tet_spheres.cpp:108-117).
+# --------------------------------------------------------------------------- #
+
+def read_veg(path: str | os.PathLike) -> tuple[np.ndarray, np.ndarray]:
+    """Read ``*VERTICES`` / ``*ELEMENTS TET`` from a Vega file.
+
+    Indices on disk are 1-based (or 0-based if the file says so by using id 0);
+    returns float64 ``[n,3]`` and 0-based int32 ``[m,4]``.
+    """
+    verts: list[list[float]] = []
+    tets: list[list[int]] = []
+    vid: list[int] = []
+    mode = None
+    header_left = 0
+    with open(path, "r") as fh:
+        for raw in fh:
+            line = raw.strip()
+            if not line or line.startswith("#"):
+                continue
+            if line.startswith("*"):
+                key = line.upper()
+                if key.startswith("*VERTICES"):
+                    mode, header_left = "v", 1
+                elif key.startswith("*ELEMENTS"):
+                    mode, header_left = "e", 2
+                else:
+                    mode = None
+                continue
+            if mode is None:
+                continue
+            if header_left:
+                header_left -= 1
+                if mode == "e" and header_left == 1 and line.upper() != "TET":
+                    raise ValueError(f"{path}: only TET elements are supported, got {line!r}")
+                continue
+            tok = line.replace(",", " ").split()
+            if mode == "v":
+                vid.append(int(tok[0]))
+                verts.append([float(tok[1]), float(tok[2]), float(tok[3])])
+            else:
+                tets.append([int(tok[1]), int(tok[2]), int(tok[3]), int(tok[4])])
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+    t = np.asarray(tets, dtype=np.int64).reshape(-1, 4)
+    base = min(vid) if vid else 1
+    return v, (t - base).astype(np.int32)
+
+
+def write_veg(path: str | os.PathLike, verts: np.ndarray, tets: np.ndarray) -> None:
+    """Write a 1-based Vega tet mesh readable by :func:`read_veg`."""
+    with open(path, "w") as fh:
+        fh.write("# Vega mesh file.\n")
+        fh.write(f"# {verts.shape[0]} vertices, {tets.shape[0]} elements\n\n*VERTICES\n")
+        fh.write(f"{verts.shape[0]} 3 0 0\n")
+        for i, p in enumerate(np.asarray(verts, dtype=np.float64)):
+            fh.write(f"{i + 1} {float(p[0])!r} {float(p[1])!r} {float(p[2])!r}\n")
+        fh.write("\n*ELEMENTS\nTET\n")
+        fh.write(f"{tets.shape[0]} 4 0\n")
+        for i, t in enumerate(np.asarray(tets, dtype=np.int64)):
+            fh.write(f"{i + 1} {t[0] + 1} {t[1] + 1} {t[2] + 1} {t[3] + 1}\n")
