@@ -1,0 +1,149 @@
+/*
+ * tssplat_amd -- C ABI of the MI355X (gfx950) tet-sphere geometry-energy path.
+ *
+ * This is the drop-in boundary for the one hot path of gmh14/tssplat: the
+ * per-iteration energy  E = c1 * 1/2 |L G x|^2 + c2 * sum_e max(-det F_e, 0)^p
+ * and its analytic gradient.  Every entry point below replaces one piece of the
+ * reference's native extension `tet_spheres.tet_spheres_ext`
+ * (citations into /root/reference/tssplat_ext/tet_spheres/):
+ *
+ *   tsamd_create            <- TetSpheres::TetSpheres(int nv, double*, int ntet, int*)   tet_spheres.cpp:119-126
+ *                              + TetSpheres::init                                        tet_spheres.cpp:140-203
+ *                              + the pybind array constructor                            tet_spheres.cpp:234-258
+ *   tsamd_create_from_veg   <- TetSpheres::TetSpheres(const std::string& filename)       tet_spheres.cpp:108-117
+ *   tsamd_destroy           <- TetSpheres::~TetSpheres                                   tet_spheres.cpp:128-138
+ *   tsamd_forward           <- tet_spheres_smooth_barrier          (forward)             tet_spheres_cuda.cu:118-195
+ *   tsamd_backward          <- tet_spheres_smooth_barrier_backward (backward)            tet_spheres_cuda.cu:197-263
+ *   tsamd_forward_backward  <- both of the above fused into one pass (no reference twin:
+ *                              the reference recomputes G x in backward, .cu:221)
+ *   tsamd_scale             <- the cublasSscal by gradH.item() at                        tet_spheres_cuda.cu:257-258
+ *   tsamd_grad_limit        <- tet_spheres_grad_limit (intended semantics, see below)    tet_spheres_cuda.cu:265-303
+ *   tsamd_num_vertices/_tets<- TetSpheres::n / ::nele                                    tet_spheres.h:40
+ *   tsamd_last_error        <- the stderr line + std::runtime_error of cudaUtils.h:10-44
+ *
+ * Plain pointers and sizes only; no torch, no C++ types.  All `*_dev` pointers
+ * are HIP device pointers on the device the handle was created on; `stream`
+ * is a hipStream_t passed as void* (NULL = the null stream).  No entry point
+ * synchronises the host with the device except tsamd_create / tsamd_destroy /
+ * tsamd_read_energy_terms.  Every function returns 0 on success and a nonzero
+ * tsamd_status otherwise; the message is available from tsamd_last_error()
+ * (thread-local).  A handle is not re-entrant: one evaluation at a time per
+ * handle (same rule as the reference's per-object scratch, tet_spheres.h:36-40).
+ */
+#ifndef TSSPLAT_AMD_H
+#define TSSPLAT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsamd_handle tsamd_handle;
+
+typedef enum tsamd_status {
+    TSAMD_OK = 0,
+    TSAMD_ERR_INVALID_ARGUMENT = 1,  /* null pointer, negative size, index out of range           */
+    TSAMD_ERR_BAD_MESH = 2,          /* non-manifold face (>2 tets), singular rest tet             */
+    TSAMD_ERR_NO_DEVICE = 3,         /* no HIP device / not a gfx950-class device                  */
+    TSAMD_ERR_HIP = 4,               /* a HIP runtime call failed (text in tsamd_last_error)       */
+    TSAMD_ERR_IO = 5,                /* tsamd_create_from_veg: unreadable or malformed file        */
+    TSAMD_ERR_TILING = 6,            /* mesh cannot be tiled into the LDS budget                   */
+    TSAMD_ERR_HOST_ONLY = 7          /* device entry point called on a host_only handle            */
+} tsamd_status;
+
+/* Zero-initialise, set struct_size = sizeof(tsamd_options), override what you need. */
+typedef struct tsamd_options {
+    int32_t struct_size;
+    int32_t device;            /* HIP device ordinal; -1 = current device                          */
+    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 163840 (all of a gfx950 CU) */
+    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 1024                      */
+    int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto            */
+    int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
+    int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
+    int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
+} tsamd_options;
+
+/* Introspection of the tiling plan (host side; valid for host_only handles too). */
+typedef struct tsamd_plan_info {
+    int64_t n_vertices, n_tets;
+    int64_t n_tiles;
+    int64_t n_components;        /* face-connected components (= tet-spheres)                       */
+    int64_t total_slots;         /* sum over tiles of owned + halo tets                             */
+    int64_t total_tile_vertices; /* sum over tiles of local vertices                                */
+    int64_t shared_vertex_copies;/* tile-vertex copies that go through the staging buffer           */
+    int64_t finish_vertices;     /* global vertices written by the finish kernel                    */
+    int64_t device_bytes;        /* bytes of plan data resident in HBM                              */
+    int32_t max_slots, max_tile_vertices, block_threads, lds_bytes;
+} tsamd_plan_info;
+
+/* One tile of the plan, as host pointers into the handle (valid until tsamd_destroy).
+ * Exists so tests can replay the exact data the kernels consume. */
+typedef struct tsamd_tile_view {
+    int32_t n_slots, n_owned, s_pad, n_verts, n_excl;
+    int64_t stage_off;
+    const uint32_t *planes;   /* 13 planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]   */
+    const int32_t *gvid;      /* n_verts global vertex ids, exclusive ones first                    */
+    const int32_t *slot_tet;  /* s_pad global tet ids (-1 = padding)                                */
+} tsamd_tile_view;
+
+const char *tsamd_last_error(void);
+const char *tsamd_version(void);
+
+/*
+ * rest_xyz: n_vertices*3 float32 (host), tets: n_tets*4 int32 (host, 0-based).
+ * Exactly the arrays energies/smooth_barrier.py:38-40 hands to TetSpheres(v_flat, f_flat).
+ * The rest shape is frozen here (positions promoted to double, Dm^-1 built in
+ * double and rounded to fp32 -- tet_spheres.cpp:252-255, :43-45).
+ */
+int tsamd_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
+                 const tsamd_options *options, tsamd_handle **out);
+int tsamd_create_from_veg(const char *path, const tsamd_options *options, tsamd_handle **out);
+void tsamd_destroy(tsamd_handle *h);
+
+int64_t tsamd_num_vertices(const tsamd_handle *h);
+int64_t tsamd_num_tets(const tsamd_handle *h);
+int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out);
+int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out);
+/* finish lists: vertex k (global id vid[k]) = sum of stage rows idx[off[k] .. off[k+1]) */
+int tsamd_get_finish_lists(const tsamd_handle *h, int64_t *n_finish, const int32_t **vid,
+                           const int32_t **off, const int32_t **idx);
+/* face adjacency computed at create time: 4 ints per tet, -1 = boundary face */
+int tsamd_get_adjacency(const tsamd_handle *h, const int32_t **nbr);
+
+/*
+ * energy_dev: 1 float, receives E = c1*E_s + c2*E_b.  x_dev: n_vertices*3 floats.
+ * order: 2 or 4 are meaningful; any other value makes the penalty term 0
+ * (tet_spheres_cuda.cu:57-63).
+ */
+int tsamd_forward(tsamd_handle *h, const float *x_dev, float c1, float c2, int order,
+                  void *stream, float *energy_dev);
+/*
+ * grad_dev: n_vertices*3 floats, overwritten with grad_out * dE/dx.
+ * grad_out_dev: 1 float on the device (the autograd grad_output), or NULL for 1.0.
+ * Read on the device: no .item() style host sync (contrast tet_spheres_cuda.cu:257).
+ */
+int tsamd_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, float c1, float c2,
+                   int order, void *stream, float *grad_dev);
+/* One pass producing both; energy_dev may be NULL. */
+int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, float c1,
+                           float c2, int order, void *stream, float *energy_dev, float *grad_dev);
+/* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
+int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
+
+/* out[i] = in[i] * (*scalar_dev); in == out allowed. */
+int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream);
+/*
+ * In-place step clamp with the semantics the reference intended
+ * (utils/optimizer.py:84-86: if max|g| > threshold: g *= s / max|g|), not the
+ * shipped bug that reads g[0] (tet_spheres_cuda.cu:278).  No host sync.
+ * workspace_dev: >= tsamd_grad_limit_workspace_bytes() bytes of scratch.
+ */
+int64_t tsamd_grad_limit_workspace_bytes(void);
+int tsamd_grad_limit(float *grad_dev, int64_t n, float s_threshold, float s, void *workspace_dev,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSSPLAT_AMD_H */

@@ -1,0 +1,137 @@
+"""float64 replay of the tile planes the HIP kernels consume -- a TEST helper.
+
+Walks the host copy of a tiling plan (through the C ABI's introspection calls)
+and performs, tile by tile, exactly the passes of
+tssplat_amd/csrc/kernels.hip::tile_energy_kernel in numpy float64, followed by
+the finish kernel's staging sum.  If this matches the oracle, the plan data
+(local indices, halo, owned flags, Dm^-1 planes, exclusive/shared vertex
+split, finish lists) is right, and a GPU mismatch can only come from the
+kernel code itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from tssplat_amd import _capi
+
+OWNED = 0x8000
+
+
+def plan_tiles(ts):
+    lib = _capi.load()
+    info = ts.plan_info()
+    for t in range(info["n_tiles"]):
+        tv = _capi.TileView()
+        _capi.check(lib.tsamd_get_tile(ts._handle(), t, C.byref(tv)))
+        sp = tv.s_pad
+        planes = np.ctypeslib.as_array(tv.planes, shape=(13, sp)).copy()
+        gvid = np.ctypeslib.as_array(tv.gvid, shape=(tv.n_verts,)).copy()
+        slot_tet = np.ctypeslib.as_array(tv.slot_tet, shape=(sp,)).copy()
+        yield dict(n_slots=tv.n_slots, n_owned=tv.n_owned, s_pad=sp, n_verts=tv.n_verts, n_excl=tv.n_excl,
+                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet)
+
+
+def finish_lists(ts):
+    lib = _capi.load()
+    n = C.c_int64()
+    vid = C.POINTER(C.c_int32)()
+    off = C.POINTER(C.c_int32)()
+    idx = C.POINTER(C.c_int32)()
+    _capi.check(lib.tsamd_get_finish_lists(ts._handle(), C.byref(n), C.byref(vid), C.byref(off), C.byref(idx)))
+    k = n.value
+    if k == 0:
+        return np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
+    off_a = np.ctypeslib.as_array(off, shape=(k + 1,)).copy()
+    ne = int(off_a[-1])
+    idx_a = np.ctypeslib.as_array(idx, shape=(max(ne, 1),)).copy()[:ne]
+    return np.ctypeslib.as_array(vid, shape=(k,)).copy(), off_a, idx_a
+
+
+def adjacency(ts):
+    lib = _capi.load()
+    p = C.POINTER(C.c_int32)()
+    _capi.check(lib.tsamd_get_adjacency(ts._handle(), C.byref(p)))
+    if ts.nele == 0:
+        return np.zeros((0, 4), np.int32)
+    return np.ctypeslib.as_array(p, shape=(ts.nele, 4)).copy()
+
+
+def _det(F):
+    return (-F[:, 0, 2] * F[:, 1, 1] * F[:, 2, 0] + F[:, 0, 1] * F[:, 1, 2] * F[:, 2, 0]
+            + F[:, 0, 2] * F[:, 1, 0] * F[:, 2, 1] - F[:, 0, 0] * F[:, 1, 2] * F[:, 2, 1]
+            - F[:, 0, 1] * F[:, 1, 0] * F[:, 2, 2] + F[:, 0, 0] * F[:, 1, 1] * F[:, 2, 2])
+
+
+def _cof(F):
+    C_ = np.empty_like(F)
+    C_[:, 0, 0] = F[:, 1, 1] * F[:, 2, 2] - F[:, 1, 2] * F[:, 2, 1]
+    C_[:, 0, 1] = F[:, 1, 2] * F[:, 2, 0] - F[:, 1, 0] * F[:, 2, 2]
+    C_[:, 0, 2] = F[:, 1, 0] * F[:, 2, 1] - F[:, 1, 1] * F[:, 2, 0]
+    C_[:, 1, 0] = F[:, 0, 2] * F[:, 2, 1] - F[:, 0, 1] * F[:, 2, 2]
+    C_[:, 1, 1] = F[:, 0, 0] * F[:, 2, 2] - F[:, 0, 2] * F[:, 2, 0]
+    C_[:, 1, 2] = F[:, 0, 1] * F[:, 2, 0] - F[:, 0, 0] * F[:, 2, 1]
+    C_[:, 2, 0] = F[:, 0, 1] * F[:, 1, 2] - F[:, 0, 2] * F[:, 1, 1]
+    C_[:, 2, 1] = F[:, 0, 2] * F[:, 1, 0] - F[:, 0, 0] * F[:, 1, 2]
+    C_[:, 2, 2] = F[:, 0, 0] * F[:, 1, 1] - F[:, 0, 1] * F[:, 1, 0]
+    return C_
+
+
+def emulate(ts, x, c1, c2, order, grad_output=1.0):
+    """Returns (E, E_s, E_b, grad[n,3]) in float64 from the plan's planes."""
+    c1 = float(np.float32(c1))
+    c2 = float(np.float32(c2))
+    x = np.asarray(x, dtype=np.float32).astype(np.float64).reshape(-1, 3)
+    n = x.shape[0]
+    grad = np.full((n, 3), np.nan)
+    info = ts.plan_info()
+    stage = np.full((max(info["shared_vertex_copies"], 1), 3), np.nan)
+    Es = Eb = 0.0
+    for T in plan_tiles(ts):
+        sp, pl = T["s_pad"], T["planes"]
+        ZS = sp
+        lv = np.stack([pl[0] & 0x7fff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
+        owned = (pl[0] & OWNED) != 0
+        assert np.array_equal(owned, (pl[2] & OWNED) != 0), "owned bit must agree in lv and nbr planes"
+        nb = np.stack([pl[2] & 0x7fff, pl[2] >> 16, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
+        dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
+        assert owned.sum() == T["n_owned"]
+        xs = x[T["gvid"]]
+        p = xs[lv]                                            # [sp,4,3]
+        Ds = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]], axis=2)
+        F = Ds @ dminv
+        J = _det(F)
+        Jm = np.maximum(-J, 0)
+        if order == 2:
+            pen, dpen = Jm ** 2, -2 * Jm
+        elif order == 4:
+            pen, dpen = Jm ** 4, -4 * Jm ** 3
+        else:
+            pen, dpen = 0 * Jm, 0 * Jm
+        Eb += float(pen[owned].sum())
+        scal = np.where(owned, c2 * dpen, 0.0)
+        Fz = np.concatenate([F.reshape(sp, 9), np.zeros((1, 9))], axis=0)      # + zero slot
+        deg = (nb != ZS).sum(axis=1).astype(np.float64)
+        H = deg[:, None] * Fz[:sp] - Fz[nb].sum(axis=1)
+        H[~owned] = 0.0
+        Es += 0.5 * float((H * H).sum())
+        Hz = np.concatenate([H, np.zeros((1, 9))], axis=0)
+        Q = deg[:, None] * Hz[:sp] - Hz[nb].sum(axis=1)
+        P = c1 * Q.reshape(sp, 3, 3) + scal[:, None, None] * _cof(F)
+        d = P @ np.transpose(dminv, (0, 2, 1))
+        gs = np.zeros((T["n_verts"], 3))
+        for k in range(3):
+            np.add.at(gs, lv[:, k + 1], d[:, :, k])
+        np.add.at(gs, lv[:, 0], -d.sum(axis=2))
+        ne = T["n_excl"]
+        assert np.all(np.isnan(grad[T["gvid"][:ne]])), "an exclusive vertex was written twice"
+        grad[T["gvid"][:ne]] = gs[:ne] * grad_output
+        stage[T["stage_off"]:T["stage_off"] + T["n_verts"] - ne] = gs[ne:]
+    vid, off, idx = finish_lists(ts)
+    for k in range(len(vid)):
+        rows = stage[idx[off[k]:off[k + 1]]]
+        assert np.all(np.isnan(grad[vid[k]])), "a finish vertex was also written as exclusive"
+        grad[vid[k]] = rows.sum(axis=0) * grad_output
+    assert not np.isnan(grad).any(), "some vertex received no gradient"
+    return c1 * Es + c2 * Eb, Es, Eb, grad

@@ -1,0 +1,78 @@
+"""In-tree build of libtssplat_amd.so with hipcc for gfx950.
+
+The shared library lands next to this file (``tssplat_amd/libtssplat_amd.so``),
+is git-ignored, and travels to the GPU box with the gpurun snapshot.  There is
+no JIT cache and no pip install: the driver records which in-tree .so files
+the GPU tests load.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(_HERE, "libtssplat_amd.so")
+_OBJ = os.path.join(_HERE, "_obj")
+ARCH = "gfx950"
+
+SOURCES = ["plan.cpp", "capi.cpp", "kernels.hip"]
+HEADERS = ["plan.h", "kernels.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
+
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]
+DEVICE_FLAGS = [f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the tssplat_amd extension cannot be built (no CPU fallback exists)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(HOST_FLAGS + DEVICE_FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile (if stale) and return the path of libtssplat_amd.so."""
+    stamp = os.path.join(_OBJ, "digest")
+    digest = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(_OBJ, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(_OBJ, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS
+        if src.endswith(".hip"):
+            cmd += DEVICE_FLAGS
+        else:
+            cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+            # host-only translation units: put -x before the file
+            cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
+                                           os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    link = [hipcc, "-shared", "-o", LIB] + objs + [f"--offload-arch={ARCH}", "-pthread"]
+    if verbose:
+        print(" ".join(link), file=sys.stderr)
+    subprocess.check_call(link)
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,129 @@
+"""ctypes binding of include/tssplat_amd.h (libtssplat_amd.so).
+
+The library is the product; this file is plumbing.  There is deliberately no
+Python/CPU fallback: if the shared library cannot be loaded, importing the
+operator surface raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+_lib = None
+
+
+class TsamdError(RuntimeError):
+    """A C-ABI call failed (the reference surfaces native failures as RuntimeError too,
+    /root/reference/tssplat_ext/tet_spheres/cudaUtils.h:10-44)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"tssplat_amd error {code}: {message}")
+        self.code = code
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("device", C.c_int32),
+        ("lds_budget_bytes", C.c_int32),
+        ("max_threads", C.c_int32),
+        ("target_owned", C.c_int32),
+        ("balance_slots", C.c_int32),
+        ("host_only", C.c_int32),
+        ("num_threads", C.c_int32),
+    ]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_int64), ("n_tets", C.c_int64), ("n_tiles", C.c_int64),
+        ("n_components", C.c_int64), ("total_slots", C.c_int64), ("total_tile_vertices", C.c_int64),
+        ("shared_vertex_copies", C.c_int64), ("finish_vertices", C.c_int64), ("device_bytes", C.c_int64),
+        ("max_slots", C.c_int32), ("max_tile_vertices", C.c_int32), ("block_threads", C.c_int32),
+        ("lds_bytes", C.c_int32),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class TileView(C.Structure):
+    _fields_ = [
+        ("n_slots", C.c_int32), ("n_owned", C.c_int32), ("s_pad", C.c_int32), ("n_verts", C.c_int32),
+        ("n_excl", C.c_int32), ("stage_off", C.c_int64),
+        ("planes", C.POINTER(C.c_uint32)), ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)),
+    ]
+
+
+# every symbol include/tssplat_amd.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "tsamd_last_error": (C.c_char_p, []),
+    "tsamd_version": (C.c_char_p, []),
+    "tsamd_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "tsamd_create_from_veg": (C.c_int, [C.c_char_p, C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "tsamd_destroy": (None, [C.c_void_p]),
+    "tsamd_num_vertices": (C.c_int64, [C.c_void_p]),
+    "tsamd_num_tets": (C.c_int64, [C.c_void_p]),
+    "tsamd_get_plan_info": (C.c_int, [C.c_void_p, C.POINTER(PlanInfo)]),
+    "tsamd_get_tile": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(TileView)]),
+    "tsamd_get_finish_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)),
+                                         C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.POINTER(C.c_int32))]),
+    "tsamd_get_adjacency": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(C.c_int32))]),
+    "tsamd_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "tsamd_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                                 C.c_void_p]),
+    "tsamd_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "tsamd_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
+    "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libtssplat_amd.so (building it in-tree first if hipcc is around and it is stale/missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing:
+        try:
+            path = _build.build()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -m tssplat_amd._build` (needs hipcc, --offload-arch=gfx950). "
+            "tssplat_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise TsamdError(rc, load().tsamd_last_error().decode("utf-8", "replace"))
+
+
+def make_options(**kw) -> Options:
+    o = Options()
+    o.struct_size = C.sizeof(Options)
+    o.device = -1
+    o.balance_slots = 1
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown tsamd option {k!r}")
+        setattr(o, k, int(v))
+    return o

@@ -1,0 +1,364 @@
+// C ABI of libtssplat_amd.so (declared in include/tssplat_amd.h).
+//
+// Owns what the reference's `struct TetSpheres` owns
+// (/root/reference/tssplat_ext/tet_spheres/tet_spheres.h:9-42): the device
+// copy of the rest-state operators and the per-evaluation scratch -- here the
+// tiling plan's planes, the staging rows for shared vertices and the per-tile
+// energy partials.  Unlike the reference destructor (tet_spheres.cpp:128-138)
+// everything allocated is freed.
+#include "../../include/tssplat_amd.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define TSAMD_HIP(call)                                                                             \
+    do {                                                                                            \
+        hipError_t e__ = (call);                                                                    \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(TSAMD_ERR_HIP, std::string(#call) + " failed: " + hipGetErrorString(e__)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool active = false;
+    hipError_t enter(int dev)
+    {
+        hipError_t e = hipGetDevice(&prev);
+        if (e != hipSuccess) return e;
+        if (prev != dev) {
+            e = hipSetDevice(dev);
+            if (e != hipSuccess) return e;
+            active = true;
+        }
+        return hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (active) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct tsamd_handle {
+    tsamd::Plan plan;
+    bool host_only = true;
+    int device = -1;
+    int64_t device_bytes = 0;
+    // device
+    tsamd::TileDesc *d_tiles = nullptr;
+    uint8_t *d_blob = nullptr;
+    int32_t *d_gvid = nullptr, *d_fin_vid = nullptr, *d_fin_off = nullptr, *d_fin_idx = nullptr;
+    float *d_stage = nullptr;
+    double *d_partials = nullptr;
+    double *d_terms = nullptr;
+    float *d_energy_scratch = nullptr;
+};
+
+namespace {
+
+template <class T>
+int upload(T *&dst, const void *src, size_t count, int64_t &bytes)
+{
+    const size_t nbytes = (count ? count : 1) * sizeof(T);
+    TSAMD_HIP(hipMalloc(reinterpret_cast<void **>(&dst), nbytes));
+    if (count && src) TSAMD_HIP(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    bytes += int64_t(nbytes);
+    return TSAMD_OK;
+}
+
+void release(tsamd_handle *h)
+{
+    if (!h) return;
+    if (!h->host_only) {
+        DeviceGuard g;
+        (void)g.enter(h->device);
+        (void)hipFree(h->d_tiles);
+        (void)hipFree(h->d_blob);
+        (void)hipFree(h->d_gvid);
+        (void)hipFree(h->d_fin_vid);
+        (void)hipFree(h->d_fin_off);
+        (void)hipFree(h->d_fin_idx);
+        (void)hipFree(h->d_stage);
+        (void)hipFree(h->d_partials);
+        (void)hipFree(h->d_terms);
+        (void)hipFree(h->d_energy_scratch);
+    }
+    delete h;
+}
+
+int to_device(tsamd_handle *h, int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(TSAMD_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU fallback)");
+    if (device < 0) TSAMD_HIP(hipGetDevice(&device));
+    if (device >= count) return fail(TSAMD_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    TSAMD_HIP(hipGetDeviceProperties(&prop, device));
+    if (size_t(h->plan.lds_bytes) > prop.sharedMemPerBlock && size_t(h->plan.lds_bytes) > prop.maxSharedMemoryPerMultiProcessor)
+        return fail(TSAMD_ERR_NO_DEVICE, std::string("device ") + prop.name + " (" + prop.gcnArchName +
+                                             ") offers less LDS per workgroup than the plan needs; built for gfx950");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(device));
+    h->device = device;
+    h->host_only = false;
+    const tsamd::Plan &P = h->plan;
+    int rc;
+    if ((rc = upload(h->d_tiles, P.tiles.data(), P.tiles.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(P.blob.data()), P.blob.size() * 4, h->device_bytes))) return rc;
+    if ((rc = upload(h->d_gvid, P.gvid.data(), P.gvid.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_fin_vid, P.fin_vid.data(), P.fin_vid.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_fin_off, P.fin_off.data(), P.fin_off.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_fin_idx, P.fin_idx.data(), P.fin_idx.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_stage, nullptr, size_t(P.n_stage) * 3, h->device_bytes))) return rc;
+    if ((rc = upload(h->d_partials, nullptr, P.tiles.size() * 2, h->device_bytes))) return rc;
+    if ((rc = upload(h->d_terms, nullptr, 2, h->device_bytes))) return rc;
+    if ((rc = upload(h->d_energy_scratch, nullptr, 1, h->device_bytes))) return rc;
+    TSAMD_HIP(hipMemset(h->d_terms, 0, 2 * sizeof(double)));
+    TSAMD_HIP(tsamd::configure_kernels(P.lds_bytes));
+    return TSAMD_OK;
+}
+
+int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, const tsamd_options *o,
+                  tsamd_handle **out)
+{
+    if (!out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    tsamd_options opt;
+    std::memset(&opt, 0, sizeof(opt));
+    opt.device = -1;
+    opt.balance_slots = 1;
+    if (o) {
+        if (o->struct_size != int32_t(sizeof(tsamd_options)))
+            return fail(TSAMD_ERR_INVALID_ARGUMENT, "tsamd_options.struct_size does not match this library");
+        opt = *o;
+    }
+    tsamd::PlanOptions po;
+    if (opt.lds_budget_bytes > 0) po.lds_budget = opt.lds_budget_bytes;
+    if (opt.max_threads > 0) po.max_threads = opt.max_threads;
+    po.target_owned = opt.target_owned;
+    po.balance = opt.balance_slots;
+    po.num_threads = opt.num_threads;
+    tsamd_handle *h = new (std::nothrow) tsamd_handle();
+    if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
+    std::string err;
+    int rc = 0;
+    try {
+        rc = tsamd::build_plan(rest, n, tets, m, po, h->plan, err);
+    } catch (const std::bad_alloc &) {
+        rc = TSAMD_ERR_INVALID_ARGUMENT;
+        err = "out of host memory while building the plan";
+    }
+    if (rc) {
+        delete h;
+        return fail(rc, err);
+    }
+    if (!opt.host_only) {
+        rc = to_device(h, opt.device);
+        if (rc) {
+            std::string keep = g_err;
+            release(h);
+            g_err = keep;
+            return rc;
+        }
+    }
+    *out = h;
+    return TSAMD_OK;
+}
+
+int check_eval(tsamd_handle *h, const float *x)
+{
+    if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "handle is null");
+    if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
+    if (!x && h->plan.n > 0) return fail(TSAMD_ERR_INVALID_ARGUMENT, "x_dev is null");
+    return TSAMD_OK;
+}
+
+int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, float c2, int order, void *stream,
+             float *energy, float *grad)
+{
+    int rc = check_eval(h, x);
+    if (rc) return rc;
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    tsamd::EvalArgs a;
+    a.tiles = h->d_tiles;
+    a.blob = h->d_blob;
+    a.gvid = h->d_gvid;
+    a.fin_vid = h->d_fin_vid;
+    a.fin_off = h->d_fin_off;
+    a.fin_idx = h->d_fin_idx;
+    a.n_tiles = int64_t(h->plan.tiles.size());
+    a.n_finish = int64_t(h->plan.fin_vid.size());
+    a.block_threads = h->plan.block_threads;
+    a.lds_bytes = h->plan.lds_bytes;
+    a.x = x;
+    a.grad_out = grad_out;
+    a.c1 = c1;
+    a.c2 = c2;
+    a.order = order;
+    a.grad = grad;
+    a.stage = h->d_stage;
+    a.partials = h->d_partials;
+    a.energy = energy;
+    a.terms = h->d_terms;
+    TSAMD_HIP(tsamd::launch_eval(a, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tsamd_last_error(void) { return g_err.c_str(); }
+const char *tsamd_version(void) { return "tssplat_amd 0.1 (gfx950)"; }
+
+int tsamd_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
+                 const tsamd_options *options, tsamd_handle **out)
+{
+    return create_common(rest_xyz, n_vertices, tets, n_tets, options, out);
+}
+
+int tsamd_create_from_veg(const char *path, const tsamd_options *options, tsamd_handle **out)
+{
+    if (!path) return fail(TSAMD_ERR_INVALID_ARGUMENT, "path is null");
+    std::vector<float> rest;
+    std::vector<int32_t> tets;
+    std::string err;
+    int rc = tsamd::read_veg(path, rest, tets, err);
+    if (rc) return fail(rc, err);
+    return create_common(rest.data(), int64_t(rest.size() / 3), tets.data(), int64_t(tets.size() / 4), options, out);
+}
+
+void tsamd_destroy(tsamd_handle *h) { release(h); }
+
+int64_t tsamd_num_vertices(const tsamd_handle *h) { return h ? h->plan.n : -1; }
+int64_t tsamd_num_tets(const tsamd_handle *h) { return h ? h->plan.m : -1; }
+
+int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out)
+{
+    if (!h || !out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    const tsamd::Plan &P = h->plan;
+    std::memset(out, 0, sizeof(*out));
+    out->n_vertices = P.n;
+    out->n_tets = P.m;
+    out->n_tiles = int64_t(P.tiles.size());
+    out->n_components = P.n_components;
+    out->total_slots = P.total_slots;
+    out->total_tile_vertices = P.total_tile_verts;
+    out->shared_vertex_copies = P.n_stage;
+    out->finish_vertices = int64_t(P.fin_vid.size());
+    out->device_bytes = h->device_bytes;
+    out->max_slots = P.max_slots;
+    out->max_tile_vertices = P.max_verts;
+    out->block_threads = P.block_threads;
+    out->lds_bytes = P.lds_bytes;
+    return TSAMD_OK;
+}
+
+int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out)
+{
+    if (!h || !out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    const tsamd::Plan &P = h->plan;
+    if (tile < 0 || tile >= int64_t(P.tiles.size())) return fail(TSAMD_ERR_INVALID_ARGUMENT, "tile out of range");
+    const tsamd::TileDesc &d = P.tiles[size_t(tile)];
+    out->n_slots = d.n_slots;
+    out->n_owned = d.n_owned;
+    out->s_pad = d.s_pad;
+    out->n_verts = d.n_verts;
+    out->n_excl = d.n_excl;
+    out->stage_off = d.stage_off;
+    out->planes = P.blob.data() + d.blob_off / 4;
+    out->gvid = P.gvid.data() + d.vert_off;
+    out->slot_tet = P.slot_tet.data() + P.slot_base[size_t(tile)];
+    return TSAMD_OK;
+}
+
+int tsamd_get_finish_lists(const tsamd_handle *h, int64_t *n_finish, const int32_t **vid, const int32_t **off,
+                           const int32_t **idx)
+{
+    if (!h || !n_finish || !vid || !off || !idx) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    *n_finish = int64_t(h->plan.fin_vid.size());
+    *vid = h->plan.fin_vid.data();
+    *off = h->plan.fin_off.data();
+    *idx = h->plan.fin_idx.data();
+    return TSAMD_OK;
+}
+
+int tsamd_get_adjacency(const tsamd_handle *h, const int32_t **nbr)
+{
+    if (!h || !nbr) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    *nbr = h->plan.nbr.data();
+    return TSAMD_OK;
+}
+
+int tsamd_forward(tsamd_handle *h, const float *x_dev, float c1, float c2, int order, void *stream,
+                  float *energy_dev)
+{
+    if (!energy_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "energy_dev is null");
+    return evaluate(h, x_dev, nullptr, c1, c2, order, stream, energy_dev, nullptr);
+}
+
+int tsamd_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, float c1, float c2, int order,
+                   void *stream, float *grad_dev)
+{
+    if (!grad_dev && h && h->plan.n > 0) return fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_dev is null");
+    return evaluate(h, x_dev, grad_out_dev, c1, c2, order, stream, nullptr, grad_dev);
+}
+
+int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, float c1, float c2,
+                           int order, void *stream, float *energy_dev, float *grad_dev)
+{
+    if (!grad_dev && h && h->plan.n > 0) return fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_dev is null");
+    return evaluate(h, x_dev, grad_out_dev, c1, c2, order, stream, energy_dev ? energy_dev : (h ? h->d_energy_scratch : nullptr),
+                    grad_dev);
+}
+
+int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
+{
+    if (!h || !terms_host2) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    TSAMD_HIP(hipMemcpyAsync(terms_host2, h->d_terms, 2 * sizeof(double), hipMemcpyDeviceToHost,
+                             static_cast<hipStream_t>(stream)));
+    TSAMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!in_dev || !scalar_dev || !out_dev))) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    TSAMD_HIP(tsamd::launch_scale(in_dev, scalar_dev, out_dev, n, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int64_t tsamd_grad_limit_workspace_bytes(void) { return 16; }
+
+int tsamd_grad_limit(float *grad_dev, int64_t n, float s_threshold, float s, void *workspace_dev, void *stream)
+{
+    if (n < 0 || (n > 0 && (!grad_dev || !workspace_dev))) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    TSAMD_HIP(tsamd::launch_grad_limit(grad_dev, n, s_threshold, s, workspace_dev, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+}  // extern "C"

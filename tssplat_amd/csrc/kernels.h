@@ -1,0 +1,37 @@
+// Launch interface between the C ABI (capi.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+
+#include "plan.h"
+
+namespace tsamd {
+
+struct EvalArgs {
+    // plan, resident in HBM
+    const TileDesc *tiles;
+    const uint8_t *blob;
+    const int32_t *gvid;
+    const int32_t *fin_vid, *fin_off, *fin_idx;
+    int64_t n_tiles, n_finish;
+    int32_t block_threads, lds_bytes;
+    // per evaluation
+    const float *x;
+    const float *grad_out;  // device scalar or nullptr
+    float c1, c2;
+    int order;
+    float *grad;            // nullptr = energy only
+    float *stage;           // [n_stage, 3]
+    double *partials;       // [n_tiles, 2]
+    float *energy;          // nullptr = skip
+    double *terms;          // [2] (E_s, E_b), always written when energy != nullptr
+};
+
+hipError_t launch_eval(const EvalArgs &a, hipStream_t stream);
+hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
+hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
+hipError_t configure_kernels(int lds_bytes);
+
+}  // namespace tsamd

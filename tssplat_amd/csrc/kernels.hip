@@ -1,0 +1,517 @@
+// gfx950 (MI355X / CDNA4) kernels for the tet-sphere geometry energy.
+//
+// One workgroup evaluates one *tile*: a cluster of up to ~3 800 tets (owned +
+// one-ring face halo) whose deformation gradients F fit the CU's 160 KiB LDS.
+// Per evaluation the tile's 13 dword planes (16-bit local indices + fp32
+// Dm^-1, 52 B per slot) stream from HBM exactly once with perfectly coalesced
+// 16 B/lane loads; F, L F, L^T L F and the vertex accumulation never leave the
+// CU.  No MFMA: 3x3 algebra at ~4 flop/B is bandwidth bound.
+//
+// What each stage stands for in the reference
+// (/root/reference/tssplat_ext/tet_spheres/tet_spheres_cuda.cu):
+//   pass 1  F = Ds Dm^-1, det, penalty     <- cusparseSpMV(G,x) :167,:221 + cuda_forward_det :48-66
+//   pass 2  H = L F, 1/2|H|^2              <- cusparseSpMV(GTLTLG,x) :131 + cublasSdot :154 (factored, no M)
+//   pass 3  P = c1 L^T H + c2 dpen cof(F)  <- cusparseSpMV(GTLTLG,x) :216 + cuda_backward_det :68-102
+//           g += P Dm^-T (LDS atomics)     <- cusparseSpMV(TRANSPOSE, G) :248
+//   finish  sum shared-vertex partials, reduce energy, * grad_out
+//                                          <- cublasSasum :185, host combine :191, cublasSscal :258
+// There is no host synchronisation anywhere (the reference blocks three times
+// per forward+backward: :154, :185, :257).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace tsamd {
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ float det3(const float *F)
+{
+    // row-major F[3*i+j]; the six products of tet_spheres_cuda.cu:24-29
+    return -F[2] * F[4] * F[6] + F[1] * F[5] * F[6] + F[2] * F[3] * F[7] - F[0] * F[5] * F[7] - F[1] * F[3] * F[8] +
+           F[0] * F[4] * F[8];
+}
+
+__device__ __forceinline__ void cof3(const float *F, float *C)
+{
+    C[0] = F[4] * F[8] - F[5] * F[7];
+    C[1] = F[5] * F[6] - F[3] * F[8];
+    C[2] = F[3] * F[7] - F[4] * F[6];
+    C[3] = F[2] * F[7] - F[1] * F[8];
+    C[4] = F[0] * F[8] - F[2] * F[6];
+    C[5] = F[1] * F[6] - F[0] * F[7];
+    C[6] = F[1] * F[5] - F[2] * F[4];
+    C[7] = F[2] * F[3] - F[0] * F[5];
+    C[8] = F[0] * F[4] - F[1] * F[3];
+}
+
+__device__ __forceinline__ uint32_t comp(const uint4 &v, int p)
+{
+    return p == 0 ? v.x : (p == 1 ? v.y : (p == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ float comp(const float4 &v, int p)
+{
+    return p == 0 ? v.x : (p == 1 ? v.y : (p == 2 ? v.z : v.w));
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// F of one slot from the staged positions and the slot's Dm^-1 (held in registers)
+__device__ __forceinline__ void slot_F(const float4 *xs, uint32_t lv0, uint32_t lv1, uint32_t lv2, uint32_t lv3,
+                                       const float4 *dm, int p, float *F)
+{
+    const float4 x0 = xs[lv0], x1 = xs[lv1], x2 = xs[lv2], x3 = xs[lv3];
+    const float Ds[9] = {x1.x - x0.x, x2.x - x0.x, x3.x - x0.x, x1.y - x0.y, x2.y - x0.y,
+                         x3.y - x0.y, x1.z - x0.z, x2.z - x0.z, x3.z - x0.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            F[3 * i + j] = Ds[3 * i + 0] * comp(dm[j], p) + Ds[3 * i + 1] * comp(dm[3 + j], p) +
+                           Ds[3 * i + 2] * comp(dm[6 + j], p);
+}
+
+struct KernelArgs {
+    const TileDesc *tiles;
+    const uint8_t *blob;
+    const int32_t *gvid;
+    const float *x;
+    const float *grad_out;
+    float *grad;
+    float *stage;
+    double *partials;
+    float c1, c2;
+    int order;
+    int n_tiles;
+    int tiles_per_xcd;
+};
+
+// BLOCK is the largest workgroup the instantiation may be launched with; it only sets the VGPR
+// budget (1024 threads = 4 waves/SIMD = 128 VGPRs, 768 = 3 waves/SIMD = 168 VGPRs).
+template <bool WITH_GRAD, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
+    // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2 and the halo
+    // planes two neighbouring tiles both read are served from it.
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = xcd * a.tiles_per_xcd + j;
+    if (j >= a.tiles_per_xcd || tile >= a.n_tiles) return;
+
+    const TileDesc td = a.tiles[tile];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int nq = td.s_pad >> 2;
+    const int SA = td.s_pad + 4;
+    const int VP = (td.n_verts + 3) & ~3;
+    const uint32_t ZS = uint32_t(td.s_pad);
+
+    float4 *FA = reinterpret_cast<float4 *>(smem);
+    float4 *FB = FA + SA;
+    float *FC = reinterpret_cast<float *>(FB + SA);
+    float4 *xs = reinterpret_cast<float4 *>(FC + SA);
+    float *gs = reinterpret_cast<float *>(xs + VP);
+    double *red = reinterpret_cast<double *>(gs + 3 * VP);
+
+    const bool active = tid < nq;
+    const uint4 *pl = reinterpret_cast<const uint4 *>(a.blob + td.blob_off);
+
+    // ---- stream the tile: 13 coalesced 16 B/lane loads per thread (4 consecutive slots each) ----
+    uint4 q_lv01 = make_uint4(0, 0, 0, 0), q_lv23 = q_lv01, q_nb01 = q_lv01, q_nb23 = q_lv01;
+    float4 dm[9];
+    if (active) {
+        q_lv01 = pl[0 * nq + tid];
+        q_lv23 = pl[1 * nq + tid];
+        q_nb01 = pl[2 * nq + tid];
+        q_nb23 = pl[3 * nq + tid];
+        const float4 *dpl = reinterpret_cast<const float4 *>(pl + 4 * nq);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
+    }
+    // ---- stage the tile's vertex positions ----
+    for (int v = tid; v < td.n_verts; v += nthr) {
+        const size_t gv = size_t(a.gvid[td.vert_off + v]) * 3;
+        xs[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
+    }
+    if (WITH_GRAD)
+        for (int i = tid; i < 3 * VP; i += nthr) gs[i] = 0.f;
+    if (tid == 0) {
+        FA[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
+        FB[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
+        FC[ZS] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
+    float scal[4] = {0.f, 0.f, 0.f, 0.f};  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
+    float e_b = 0.f, e_s = 0.f;
+    if (active) {
+        float f8[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
+            const bool owned = (w0 & kOwnedBit) != 0;
+            float F[9];
+            slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
+            const float J = det3(F);
+            const float Jm = fmaxf(-J, 0.f);
+            float pen = 0.f, dpen = 0.f;
+            if (a.order == 2) {
+                pen = Jm * Jm;
+                dpen = -2.f * Jm;
+            } else if (a.order == 4) {
+                pen = Jm * Jm * Jm * Jm;
+                dpen = -4.f * Jm * Jm * Jm;
+            }
+            if (owned) {
+                e_b += pen;
+                scal[p] = a.c2 * dpen;
+            }
+            const int s = 4 * tid + p;
+            FA[s] = make_float4(F[0], F[1], F[2], F[3]);
+            FB[s] = make_float4(F[4], F[5], F[6], F[7]);
+            f8[p] = F[8];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        reinterpret_cast<float4 *>(FC)[tid] = make_float4(f8[0], f8[1], f8[2], f8[3]);
+    }
+    __syncthreads();
+
+    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
+    float H[4][9];
+    if (active) {
+        const float4 own8 = reinterpret_cast<const float4 *>(FC)[tid];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
+            const bool owned = (n01 & kOwnedBit) != 0;
+            const uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
+            const int s = 4 * tid + p;
+            const float4 fa = FA[s], fb = FB[s];
+            const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
+            float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
+                            deg * fb.y, deg * fb.z, deg * fb.w, deg * comp(own8, p)};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 ga = FA[nb[k]], gb = FB[nb[k]];
+                const float gc = FC[nb[k]];
+                acc[0] -= ga.x; acc[1] -= ga.y; acc[2] -= ga.z; acc[3] -= ga.w;
+                acc[4] -= gb.x; acc[5] -= gb.y; acc[6] -= gb.z; acc[7] -= gb.w;
+                acc[8] -= gc;
+            }
+            float sq = 0.f;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                acc[c] = owned ? acc[c] : 0.f;
+                sq += acc[c] * acc[c];
+                H[p][c] = acc[c];
+            }
+            e_s += 0.5f * sq;
+            __builtin_amdgcn_sched_barrier(0);  // keep one slot's gathers in flight, not four (VGPR budget)
+        }
+    }
+    __syncthreads();  // every read of F is done; overwrite it with H in place
+
+    if (WITH_GRAD) {
+        if (active) {
+            // Dm^-1 and the vertex ids are needed again by the scatter.  Re-issuing their 11 loads here (L2-resident: the
+            // tile was streamed microseconds ago) instead of pinning 36 VGPRs across pass 2 keeps
+            // the kernel inside 128 VGPRs = 16 waves/CU.
+            q_lv01 = pl[0 * nq + tid];
+            q_lv23 = pl[1 * nq + tid];
+            const float4 *dpl = reinterpret_cast<const float4 *>(pl + 4 * nq);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int s = 4 * tid + p;
+                FA[s] = make_float4(H[p][0], H[p][1], H[p][2], H[p][3]);
+                FB[s] = make_float4(H[p][4], H[p][5], H[p][6], H[p][7]);
+            }
+            reinterpret_cast<float4 *>(FC)[tid] = make_float4(H[0][8], H[1][8], H[2][8], H[3][8]);
+        }
+        __syncthreads();
+
+        // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  scatter P Dm^-T to the tile's vertices ----
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
+                const uint32_t lv[4] = {w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
+                const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
+                const uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
+                const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
+                // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
+                const int so = 4 * tid + p;
+                const float4 ha = FA[so], hb = FB[so];
+                float P[9] = {deg * ha.x, deg * ha.y, deg * ha.z, deg * ha.w, deg * hb.x,
+                              deg * hb.y, deg * hb.z, deg * hb.w, deg * FC[so]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 ga = FA[nb[k]], gb = FB[nb[k]];
+                    const float gc = FC[nb[k]];
+                    P[0] -= ga.x; P[1] -= ga.y; P[2] -= ga.z; P[3] -= ga.w;
+                    P[4] -= gb.x; P[5] -= gb.y; P[6] -= gb.z; P[7] -= gb.w;
+                    P[8] -= gc;
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) P[c] *= a.c1;
+                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
+                    float F[9], C[9];
+                    slot_F(xs, lv[0], lv[1], lv[2], lv[3], dm, p, F);
+                    cof3(F, C);
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) P[c] += scal[p] * C[c];
+                }
+                // dE/dDs = P Dm^-T : d[i][k] = sum_j P[i][j] Dminv[k][j]; column k -> vertex k+1
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    float tot = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float d = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
+                                        P[3 * i + 2] * comp(dm[3 * k + 2], p);
+                        atomicAdd(&gs[3 * lv[k + 1] + i], d);
+                        tot += d;
+                    }
+                    atomicAdd(&gs[3 * lv[0] + i], -tot);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+
+        // ---- write out: exclusive vertices straight to grad, shared ones to the staging rows ----
+        const float gscale = a.grad_out ? *a.grad_out : 1.f;
+        const int n_ex3 = 3 * td.n_excl, n_all3 = 3 * td.n_verts;
+        for (int i = tid; i < n_ex3; i += nthr) {
+            const int v = i / 3, c = i - 3 * v;
+            a.grad[size_t(a.gvid[td.vert_off + v]) * 3 + c] = gs[i] * gscale;
+        }
+        float *st = a.stage + size_t(td.stage_off) * 3;
+        for (int i = n_ex3 + tid; i < n_all3; i += nthr) st[i - n_ex3] = gs[i];
+    }
+
+    // ---- deterministic block reduction of the two energy terms (fixed order, double) ----
+    double ds = wave_sum(double(e_s)), db = wave_sum(double(e_b));
+    const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
+    if (lane == 0) {
+        red[2 * wave] = ds;
+        red[2 * wave + 1] = db;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0, b = 0.0;
+        for (int w = 0; w < nw; ++w) {
+            s += red[2 * w];
+            b += red[2 * w + 1];
+        }
+        a.partials[2 * size_t(tile)] = s;
+        a.partials[2 * size_t(tile) + 1] = b;
+    }
+}
+
+struct FinishArgs {
+    const int32_t *fin_vid, *fin_off, *fin_idx;
+    int64_t n_finish;
+    const float *stage;
+    float *grad;
+    const float *grad_out;
+    const double *partials;
+    int64_t n_tiles;
+    float c1, c2;
+    float *energy;
+    double *terms;
+};
+
+// Vertices touched by several tiles: sum their staged partial gradients in plan order
+// (deterministic).  The last workgroup folds the per-tile energy partials, again in fixed order.
+__global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
+{
+    __shared__ double red[2 * 256];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == gridDim.x - 1) {
+        if (!a.energy) return;
+        double s = 0.0, b = 0.0;
+        for (int64_t t = tid; t < a.n_tiles; t += 256) {
+            s += a.partials[2 * t];
+            b += a.partials[2 * t + 1];
+        }
+        red[tid] = s;
+        red[256 + tid] = b;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) {
+                red[tid] += red[tid + off];
+                red[256 + tid] += red[256 + tid + off];
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            a.terms[0] = red[0];
+            a.terms[1] = red[256];
+            a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[256]);
+        }
+        return;
+    }
+    if (!a.grad) return;
+    const float gscale = a.grad_out ? *a.grad_out : 1.f;
+    const int64_t stride = int64_t(gridDim.x - 1) * 256;
+    for (int64_t k = int64_t(blockIdx.x) * 256 + tid; k < a.n_finish; k += stride) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int32_t e = a.fin_off[k]; e < a.fin_off[k + 1]; ++e) {
+            const float *r = a.stage + size_t(a.fin_idx[e]) * 3;
+            gx += r[0];
+            gy += r[1];
+            gz += r[2];
+        }
+        float *g = a.grad + size_t(a.fin_vid[k]) * 3;
+        g[0] = gx * gscale;
+        g[1] = gy * gscale;
+        g[2] = gz * gscale;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float *in, const float *scalar, float *out, int64_t n)
+{
+    const float s = *scalar;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    const int64_t n4 = n >> 2;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    const bool vec = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (vec) {
+        for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 v = in4[i];
+            out4[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+        }
+        for (int64_t i = 4 * n4 + int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * s;
+    } else {
+        for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * s;
+    }
+}
+
+// max |g| over the array, as the bit pattern of a non-negative float (monotone under uint compare)
+__global__ __launch_bounds__(256) void absmax_kernel(const float *g, int64_t n, unsigned int *out)
+{
+    __shared__ float red[256 / kWave];
+    float m = 0.f;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, kWave));
+    if (threadIdx.x % kWave == 0) red[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) m = fmaxf(m, red[w]);
+        atomicMax(out, __float_as_uint(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void clamp_kernel(float *g, int64_t n, const unsigned int *mx, float thr, float s)
+{
+    const float m = __uint_as_float(*mx);
+    if (!(m > thr)) return;
+    const float f = s / m;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) g[i] *= f;
+}
+
+int grid_for(int64_t n, int per_block, int cap)
+{
+    int64_t b = (n + per_block - 1) / per_block;
+    return int(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+hipError_t configure_kernels(int lds_bytes)
+{
+    const void *fns[4] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024>),
+                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024>),
+                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 768>),
+                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 768>)};
+    for (const void *fn : fns) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_eval(const EvalArgs &e, hipStream_t stream)
+{
+    if (e.n_tiles > 0) {
+        KernelArgs k;
+        k.tiles = e.tiles;
+        k.blob = e.blob;
+        k.gvid = e.gvid;
+        k.x = e.x;
+        k.grad_out = e.grad_out;
+        k.grad = e.grad;
+        k.stage = e.stage;
+        k.partials = e.partials;
+        k.c1 = e.c1;
+        k.c2 = e.c2;
+        k.order = e.order;
+        k.n_tiles = int(e.n_tiles);
+        k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
+        const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
+        const bool small = e.block_threads <= 768;
+        if (e.grad && small)
+            hipLaunchKernelGGL((tile_energy_kernel<true, 768>), grid, block, size_t(e.lds_bytes), stream, k);
+        else if (e.grad)
+            hipLaunchKernelGGL((tile_energy_kernel<true, 1024>), grid, block, size_t(e.lds_bytes), stream, k);
+        else if (small)
+            hipLaunchKernelGGL((tile_energy_kernel<false, 768>), grid, block, size_t(e.lds_bytes), stream, k);
+        else
+            hipLaunchKernelGGL((tile_energy_kernel<false, 1024>), grid, block, size_t(e.lds_bytes), stream, k);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    FinishArgs f;
+    f.fin_vid = e.fin_vid;
+    f.fin_off = e.fin_off;
+    f.fin_idx = e.fin_idx;
+    f.n_finish = e.grad ? e.n_finish : 0;
+    f.stage = e.stage;
+    f.grad = e.grad;
+    f.grad_out = e.grad_out;
+    f.partials = e.partials;
+    f.n_tiles = e.n_tiles;
+    f.c1 = e.c1;
+    f.c2 = e.c2;
+    f.energy = e.energy;
+    f.terms = e.terms;
+    if (f.n_finish == 0 && !f.energy) return hipSuccess;
+    const int vb = f.n_finish > 0 ? grid_for(f.n_finish, 256, 2048) : 0;
+    hipLaunchKernelGGL(finish_kernel, dim3(unsigned(vb + 1)), dim3(256), 0, stream, f);
+    return hipGetLastError();
+}
+
+hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_kernel, dim3(unsigned(grid_for(n, 1024, 2048))), dim3(256), 0, stream, in, scalar, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    unsigned int *mx = static_cast<unsigned int *>(workspace);
+    hipError_t e = hipMemsetAsync(mx, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    const int g = grid_for(n, 1024, 2048);
+    hipLaunchKernelGGL(absmax_kernel, dim3(unsigned(g)), dim3(256), 0, stream, grad, n, mx);
+    hipLaunchKernelGGL(clamp_kernel, dim3(unsigned(g)), dim3(256), 0, stream, grad, n, mx, thr, s);
+    return hipGetLastError();
+}
+
+}  // namespace tsamd

@@ -1,0 +1,726 @@
+// Host-side construction of the tiling plan: face adjacency, connected
+// components (= tet-spheres), recursive coordinate bisection into LDS-sized
+// tiles with a one-ring face halo, per-tile local indexing, and the staging /
+// finish lists for vertices that more than one tile touches.
+//
+// Replaces the role of libpgo in the reference's constructor
+// (/root/reference/tssplat_ext/tet_spheres/tet_spheres.cpp:140-159): there the
+// rest mesh becomes two global COO matrices, here it becomes per-tile planes
+// of Dm^-1 (double -> fp32, as tet_spheres.cpp:43-45 rounds the matrix values)
+// plus 16-bit local vertex / neighbour indices.  Pure C++17, no HIP.
+#include "plan.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <limits>
+#include <numeric>
+#include <sstream>
+#include <thread>
+
+namespace tsamd {
+namespace {
+
+enum { OK = 0, ERR_INVALID = 1, ERR_BAD_MESH = 2, ERR_IO = 5, ERR_TILING = 6 };
+
+// ---- tiny work-sharing helper: fn(begin, end, worker) over [0, n) in dynamic chunks ----
+template <class Fn>
+void parallel_chunks(int64_t n, int64_t chunk, int nthreads, Fn fn)
+{
+    if (n <= 0) return;
+    nthreads = std::max(1, nthreads);
+    if (nthreads == 1 || n <= chunk) {
+        fn(int64_t(0), n, 0);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto body = [&](int worker) {
+        for (;;) {
+            int64_t b = next.fetch_add(chunk, std::memory_order_relaxed);
+            if (b >= n) break;
+            fn(b, std::min(n, b + chunk), worker);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; ++t) pool.emplace_back(body, t);
+    body(0);
+    for (auto &th : pool) th.join();
+}
+
+inline void sort3(uint32_t &a, uint32_t &b, uint32_t &c)
+{
+    if (a > b) std::swap(a, b);
+    if (b > c) std::swap(b, c);
+    if (a > b) std::swap(a, b);
+}
+
+struct BucketFace {
+    uint32_t b, c, slot;  // the smallest vertex is the bucket id; slot = 4*tet + opposite local vertex
+};
+
+// nbr[4e+k] = tet across the face of e opposite local vertex k, -1 on the boundary.
+int build_adjacency(const int32_t *tets, int64_t n, int64_t m, std::vector<int32_t> &nbr, int nthreads,
+                    std::string &err)
+{
+    static const int opp[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+    nbr.assign(size_t(4 * m), -1);
+    std::vector<int64_t> start(size_t(n + 1), 0);
+    for (int64_t e = 0; e < m; ++e) {
+        const int32_t *t = tets + 4 * e;
+        for (int k = 0; k < 4; ++k) {
+            uint32_t a = t[opp[k][0]], b = t[opp[k][1]], c = t[opp[k][2]];
+            sort3(a, b, c);
+            ++start[a + 1];
+        }
+    }
+    for (int64_t v = 0; v < n; ++v) start[v + 1] += start[v];
+    std::vector<BucketFace> faces(size_t(4 * m));
+    {
+        std::vector<int64_t> cur(start.begin(), start.end() - 1);
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t *t = tets + 4 * e;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t a = t[opp[k][0]], b = t[opp[k][1]], c = t[opp[k][2]];
+                sort3(a, b, c);
+                faces[size_t(cur[a]++)] = BucketFace{b, c, uint32_t(4 * e + k)};
+            }
+        }
+    }
+    std::atomic<int> bad{0};
+    parallel_chunks(n, 4096, nthreads, [&](int64_t vb, int64_t ve, int) {
+        for (int64_t v = vb; v < ve; ++v) {
+            BucketFace *f0 = faces.data() + start[v], *f1 = faces.data() + start[v + 1];
+            std::sort(f0, f1, [](const BucketFace &x, const BucketFace &y) {
+                return x.b != y.b ? x.b < y.b : (x.c != y.c ? x.c < y.c : x.slot < y.slot);
+            });
+            for (BucketFace *f = f0; f + 1 < f1; ++f) {
+                if (f->b == f[1].b && f->c == f[1].c) {
+                    if (f + 2 < f1 && f[2].b == f->b && f[2].c == f->c) {
+                        bad.store(1);
+                        return;
+                    }
+                    nbr[f->slot] = int32_t(f[1].slot >> 2);
+                    nbr[f[1].slot] = int32_t(f->slot >> 2);
+                    ++f;
+                }
+            }
+        }
+    });
+    if (bad.load()) {
+        err = "non-manifold tet mesh: a face is shared by more than two tets";
+        return ERR_BAD_MESH;
+    }
+    return OK;
+}
+
+// per-worker scratch with O(1) reset through stamps
+struct Scratch {
+    std::vector<int32_t> tet_stamp, tet_slot, vert_stamp, vert_local;
+    int32_t stamp = 0;
+    void init(int64_t m, int64_t n)
+    {
+        if (int64_t(tet_stamp.size()) != m) {
+            tet_stamp.assign(size_t(m), 0);
+            tet_slot.assign(size_t(m), 0);
+        }
+        if (int64_t(vert_stamp.size()) != n) {
+            vert_stamp.assign(size_t(n), 0);
+            vert_local.assign(size_t(n), 0);
+        }
+    }
+    int32_t next()
+    {
+        if (stamp > std::numeric_limits<int32_t>::max() - 8) {
+            std::fill(tet_stamp.begin(), tet_stamp.end(), 0);
+            std::fill(vert_stamp.begin(), vert_stamp.end(), 0);
+            stamp = 0;
+        }
+        stamp += 2;
+        return stamp;  // `stamp` marks owned, `stamp+1` marks halo
+    }
+};
+
+struct Limits {
+    int64_t budget;
+    int64_t max_spad;
+    bool fits(int64_t n_slots, int64_t n_verts) const
+    {
+        const int64_t sp = (n_slots + 3) & ~int64_t(3);
+        return sp <= max_spad && n_verts <= 32767 && tile_lds_bytes(sp, n_verts) <= budget;
+    }
+};
+
+struct Mesh {
+    const float *rest;
+    const int32_t *tets;
+    const int32_t *nbr;
+    int64_t n, m;
+};
+
+// owned + one-ring halo size and the number of distinct vertices they touch
+void measure(const Mesh &M, const int32_t *owned, int64_t cnt, Scratch &S, int64_t &n_slots, int64_t &n_verts,
+             std::vector<int32_t> *halo_out = nullptr)
+{
+    const int32_t so = S.next(), sh = so + 1;
+    for (int64_t i = 0; i < cnt; ++i) S.tet_stamp[owned[i]] = so;
+    int64_t halo = 0, verts = 0;
+    if (halo_out) halo_out->clear();
+    auto touch = [&](int32_t e) {
+        for (int a = 0; a < 4; ++a) {
+            int32_t v = M.tets[4 * int64_t(e) + a];
+            if (S.vert_stamp[v] != so) {
+                S.vert_stamp[v] = so;
+                ++verts;
+            }
+        }
+    };
+    for (int64_t i = 0; i < cnt; ++i) {
+        const int32_t e = owned[i];
+        touch(e);
+        for (int k = 0; k < 4; ++k) {
+            int32_t q = M.nbr[4 * int64_t(e) + k];
+            if (q < 0) continue;
+            int32_t st = S.tet_stamp[q];
+            if (st == so || st == sh) continue;
+            S.tet_stamp[q] = sh;
+            ++halo;
+            if (halo_out) halo_out->push_back(q);
+            touch(q);
+        }
+    }
+    n_slots = cnt + halo;
+    n_verts = verts;
+}
+
+inline uint32_t spread10(uint32_t v)
+{
+    v &= 0x3ff;
+    v = (v | (v << 16)) & 0x030000ff;
+    v = (v | (v << 8)) & 0x0300f00f;
+    v = (v | (v << 4)) & 0x030c30c3;
+    v = (v | (v << 2)) & 0x09249249;
+    return v;
+}
+
+struct Splitter {
+    const Mesh &M;
+    const Limits &lim;
+    const std::vector<float> &cen;  // 3 per tet
+    Scratch &S;
+    std::vector<std::vector<int32_t>> &out;
+    std::string &err;
+    int rc = OK;
+
+    void bbox(const int32_t *ids, int64_t cnt, float lo[3], float hi[3]) const
+    {
+        for (int d = 0; d < 3; ++d) {
+            lo[d] = std::numeric_limits<float>::max();
+            hi[d] = -std::numeric_limits<float>::max();
+        }
+        for (int64_t i = 0; i < cnt; ++i)
+            for (int d = 0; d < 3; ++d) {
+                float c = cen[3 * size_t(ids[i]) + d];
+                lo[d] = std::min(lo[d], c);
+                hi[d] = std::max(hi[d], c);
+            }
+    }
+
+    void emit(int32_t *ids, int64_t cnt)
+    {
+        // order the leaf along a Morton curve so that lanes of a wave hold nearby tets
+        float lo[3], hi[3];
+        bbox(ids, cnt, lo, hi);
+        std::vector<std::pair<uint32_t, int32_t>> key(static_cast<size_t>(cnt));
+        for (int64_t i = 0; i < cnt; ++i) {
+            uint32_t code = 0;
+            for (int d = 0; d < 3; ++d) {
+                float ext = hi[d] - lo[d];
+                float u = ext > 0 ? (cen[3 * size_t(ids[i]) + d] - lo[d]) / ext : 0.f;
+                code |= spread10(uint32_t(std::min(1023.f, u * 1023.f))) << d;
+            }
+            key[size_t(i)] = {code, ids[i]};
+        }
+        std::sort(key.begin(), key.end());
+        std::vector<int32_t> t(static_cast<size_t>(cnt));
+        for (int64_t i = 0; i < cnt; ++i) t[size_t(i)] = key[size_t(i)].second;
+        out.push_back(std::move(t));
+    }
+
+    void split(int32_t *ids, int64_t cnt, int64_t k)
+    {
+        if (rc) return;
+        if (k <= 1) {
+            int64_t ns, nv;
+            measure(M, ids, cnt, S, ns, nv);
+            if (lim.fits(ns, nv)) {
+                emit(ids, cnt);
+                return;
+            }
+            if (cnt <= 1) {
+                err = "a single tet with its face neighbours exceeds the LDS budget";
+                rc = ERR_TILING;
+                return;
+            }
+            k = 2;
+        }
+        float lo[3], hi[3];
+        bbox(ids, cnt, lo, hi);
+        int ax = 0;
+        for (int d = 1; d < 3; ++d)
+            if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+        const int64_t k1 = k / 2;
+        int64_t mid = cnt * k1 / k;
+        mid = std::max<int64_t>(1, std::min(cnt - 1, mid));
+        std::nth_element(ids, ids + mid, ids + cnt, [&](int32_t a, int32_t b) {
+            float ca = cen[3 * size_t(a) + ax], cb = cen[3 * size_t(b) + ax];
+            return ca != cb ? ca < cb : a < b;
+        });
+        split(ids, mid, k1);
+        split(ids + mid, cnt - mid, k - k1);
+    }
+};
+
+}  // namespace
+
+int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt, Plan &P,
+               std::string &err)
+{
+    if (n < 0 || m < 0 || (n > 0 && !rest) || (m > 0 && !tets)) {
+        err = "null pointer or negative size";
+        return ERR_INVALID;
+    }
+    if (n >= (int64_t(1) << 31) / 3 || m >= (int64_t(1) << 29)) {
+        err = "mesh too large for 32-bit indexing";
+        return ERR_INVALID;
+    }
+    for (int64_t i = 0; i < 4 * m; ++i)
+        if (tets[i] < 0 || tets[i] >= n) {
+            err = "tet index out of range at flat position " + std::to_string(i);
+            return ERR_INVALID;
+        }
+    int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
+    nthreads = std::max(1, std::min(nthreads, 64));
+    int max_threads = opt.max_threads > 0 ? opt.max_threads : 1024;
+    max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
+    Limits lim;
+    lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 160 * 1024;
+    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 32764);  // slot ids share a halfword with the owned bit
+    if (lim.budget < tile_lds_bytes(8, 8)) {
+        err = "lds_budget_bytes too small";
+        return ERR_INVALID;
+    }
+
+    P = Plan();
+    P.n = n;
+    P.m = m;
+    int rc = build_adjacency(tets, n, m, P.nbr, nthreads, err);
+    if (rc) return rc;
+    Mesh M{rest, tets, P.nbr.data(), n, m};
+
+    // ---- connected components over face adjacency (each tet-sphere is one) ----
+    std::vector<int32_t> comp(size_t(m), -1);
+    std::vector<int64_t> comp_start;
+    std::vector<int32_t> comp_tets(static_cast<size_t>(m));
+    {
+        int64_t filled = 0;
+        std::vector<int32_t> stack;
+        for (int64_t s = 0; s < m; ++s) {
+            if (comp[size_t(s)] >= 0) continue;
+            const int32_t c = int32_t(comp_start.size());
+            comp_start.push_back(filled);
+            comp[size_t(s)] = c;
+            stack.push_back(int32_t(s));
+            const int64_t first = filled;
+            while (!stack.empty()) {
+                int32_t e = stack.back();
+                stack.pop_back();
+                comp_tets[size_t(filled++)] = e;
+                for (int k = 0; k < 4; ++k) {
+                    int32_t q = P.nbr[4 * size_t(e) + k];
+                    if (q >= 0 && comp[size_t(q)] < 0) {
+                        comp[size_t(q)] = c;
+                        stack.push_back(q);
+                    }
+                }
+            }
+            std::sort(comp_tets.begin() + first, comp_tets.begin() + filled);
+        }
+        comp_start.push_back(filled);
+    }
+    const int64_t C = int64_t(comp_start.size()) - 1;
+    P.n_components = C;
+
+    // ---- tet centroids (rest state) ----
+    std::vector<float> cen(static_cast<size_t>(3 * m));
+    parallel_chunks(m, 1 << 16, nthreads, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; ++i)
+            for (int d = 0; d < 3; ++d) {
+                float s = 0.f;
+                for (int a = 0; a < 4; ++a) s += rest[3 * size_t(tets[4 * i + a]) + d];
+                cen[3 * size_t(i) + d] = 0.25f * s;
+            }
+    });
+
+    std::vector<Scratch> scratch(static_cast<size_t>(nthreads));
+    auto get_scratch = [&](int w) -> Scratch & {
+        scratch[size_t(w)].init(m, n);
+        return scratch[size_t(w)];
+    };
+
+    // ---- which components fit into one tile as they are (no halo)? ----
+    std::vector<int64_t> comp_verts(static_cast<size_t>(C), 0);
+    std::vector<uint8_t> comp_fits(static_cast<size_t>(C), 0);
+    parallel_chunks(C, 16, nthreads, [&](int64_t b, int64_t e, int w) {
+        Scratch &S = get_scratch(w);
+        for (int64_t c = b; c < e; ++c) {
+            int64_t cnt = comp_start[c + 1] - comp_start[c], ns, nv;
+            if (cnt > lim.max_spad) continue;
+            measure(M, comp_tets.data() + comp_start[c], cnt, S, ns, nv);
+            comp_verts[size_t(c)] = nv;
+            comp_fits[size_t(c)] = lim.fits(ns, nv) ? 1 : 0;
+        }
+    });
+
+    // ---- group: pack small components together, bisect large ones ----
+    // group g covers components [gb, ge); a group of one non-fitting component is bisected.
+    struct Group {
+        int64_t cb, ce;
+        bool bisect;
+    };
+    std::vector<Group> groups;
+    {
+        int64_t c = 0;
+        while (c < C) {
+            if (!comp_fits[size_t(c)]) {
+                groups.push_back({c, c + 1, true});
+                ++c;
+                continue;
+            }
+            int64_t tets_sum = 0, verts_sum = 0, ce = c;
+            while (ce < C && comp_fits[size_t(ce)]) {
+                int64_t t2 = tets_sum + (comp_start[ce + 1] - comp_start[ce]);
+                int64_t v2 = verts_sum + comp_verts[size_t(ce)];  // upper bound on the union
+                if (ce > c && !lim.fits(t2, v2)) break;
+                tets_sum = t2;
+                verts_sum = v2;
+                ++ce;
+            }
+            groups.push_back({c, ce, false});
+            c = ce;
+        }
+    }
+    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 144) / 43);
+    int64_t target = opt.target_owned > 0 ? opt.target_owned : int64_t(0.70 * double(s_cap));
+    target = std::max<int64_t>(1, target);
+
+    std::vector<std::vector<std::vector<int32_t>>> group_tiles(groups.size());
+    std::atomic<int> first_rc{0};
+    std::string split_err;
+    std::atomic<bool> err_set{false};
+    parallel_chunks(int64_t(groups.size()), 1, nthreads, [&](int64_t b, int64_t e, int w) {
+        Scratch &S = get_scratch(w);
+        for (int64_t g = b; g < e; ++g) {
+            const Group &G = groups[size_t(g)];
+            int32_t *ids = comp_tets.data() + comp_start[G.cb];
+            int64_t cnt = comp_start[G.ce] - comp_start[G.cb];
+            if (!G.bisect) {
+                group_tiles[size_t(g)].emplace_back(ids, ids + cnt);
+                continue;
+            }
+            std::string local_err;
+            Splitter sp{M, lim, cen, S, group_tiles[size_t(g)], local_err};
+            sp.split(ids, cnt, (cnt + target - 1) / target);
+            if (sp.rc) {
+                first_rc.store(sp.rc);
+                bool expected = false;
+                if (err_set.compare_exchange_strong(expected, true)) split_err = local_err;
+            }
+        }
+    });
+    if (first_rc.load()) {
+        err = split_err;
+        return first_rc.load();
+    }
+
+    std::vector<std::vector<int32_t>> tiles_owned;
+    for (auto &gt : group_tiles)
+        for (auto &t : gt) tiles_owned.push_back(std::move(t));
+    group_tiles.clear();
+    const int64_t T = int64_t(tiles_owned.size());
+
+    // ---- pass A: per-tile halo + vertex lists, global per-vertex tile count ----
+    std::vector<std::vector<int32_t>> tile_halo(static_cast<size_t>(T)), tile_verts(static_cast<size_t>(T));
+    std::vector<std::atomic<int32_t>> vcount(static_cast<size_t>(n));
+    for (auto &a : vcount) a.store(0, std::memory_order_relaxed);
+    parallel_chunks(T, 4, nthreads, [&](int64_t b, int64_t e, int w) {
+        Scratch &S = get_scratch(w);
+        for (int64_t t = b; t < e; ++t) {
+            const auto &own = tiles_owned[size_t(t)];
+            int64_t ns, nv;
+            measure(M, own.data(), int64_t(own.size()), S, ns, nv, &tile_halo[size_t(t)]);
+            auto &tv = tile_verts[size_t(t)];
+            tv.reserve(size_t(nv));
+            const int32_t st = S.next();
+            auto touch = [&](int32_t el) {
+                for (int a = 0; a < 4; ++a) {
+                    int32_t v = tets[4 * int64_t(el) + a];
+                    if (S.vert_stamp[v] != st) {
+                        S.vert_stamp[v] = st;
+                        tv.push_back(v);
+                    }
+                }
+            };
+            for (int32_t el : own) touch(el);
+            for (int32_t el : tile_halo[size_t(t)]) touch(el);
+            for (int32_t v : tv) vcount[size_t(v)].fetch_add(1, std::memory_order_relaxed);
+        }
+    });
+
+    // ---- offsets ----
+    P.tiles.resize(size_t(T));
+    P.slot_base.resize(size_t(T) + 1);
+    int64_t blob_bytes = 0, vert_off = 0, stage_off = 0, slot_off = 0;
+    int32_t max_quads = 1;
+    for (int64_t t = 0; t < T; ++t) {
+        TileDesc &d = P.tiles[size_t(t)];
+        std::memset(&d, 0, sizeof(d));
+        auto &tv = tile_verts[size_t(t)];
+        // exclusive vertices first (stable)
+        std::stable_partition(tv.begin(), tv.end(),
+                              [&](int32_t v) { return vcount[size_t(v)].load(std::memory_order_relaxed) == 1; });
+        int32_t n_excl = 0;
+        for (int32_t v : tv) n_excl += vcount[size_t(v)].load(std::memory_order_relaxed) == 1;
+        d.n_owned = int32_t(tiles_owned[size_t(t)].size());
+        d.n_slots = d.n_owned + int32_t(tile_halo[size_t(t)].size());
+        d.s_pad = (d.n_slots + 3) & ~3;
+        d.n_verts = int32_t(tv.size());
+        d.n_excl = n_excl;
+        d.blob_off = uint64_t(blob_bytes);
+        d.vert_off = int32_t(vert_off);
+        d.stage_off = stage_off;
+        blob_bytes += (int64_t(kPlanes) * d.s_pad * 4 + 127) & ~int64_t(127);
+        vert_off += d.n_verts;
+        stage_off += d.n_verts - d.n_excl;
+        P.slot_base[size_t(t)] = slot_off;
+        slot_off += d.s_pad;
+        P.total_slots += d.n_slots;
+        P.max_slots = std::max(P.max_slots, d.n_slots);
+        P.max_verts = std::max(P.max_verts, d.n_verts);
+        P.lds_bytes = std::max<int32_t>(P.lds_bytes, int32_t(tile_lds_bytes(d.s_pad, d.n_verts)));
+        max_quads = std::max(max_quads, d.s_pad / 4);
+        if (vert_off >= (int64_t(1) << 31)) {
+            err = "too many tile vertices for 32-bit offsets";
+            return ERR_TILING;
+        }
+    }
+    P.slot_base[size_t(T)] = slot_off;
+    P.total_tile_verts = vert_off;
+    P.n_stage = stage_off;
+    P.block_threads = std::min(max_threads, ((max_quads + 63) / 64) * 64);
+    P.blob.assign(size_t(blob_bytes / 4), 0u);
+    P.gvid.resize(size_t(vert_off));
+    P.slot_tet.assign(size_t(slot_off), -1);
+
+    // ---- pass B: fill planes ----
+    std::atomic<int> singular{0};
+    const bool balance = opt.balance != 0;
+    parallel_chunks(T, 2, nthreads, [&](int64_t b, int64_t e, int w) {
+        Scratch &S = get_scratch(w);
+        for (int64_t t = b; t < e; ++t) {
+            const TileDesc &d = P.tiles[size_t(t)];
+            const auto &own = tiles_owned[size_t(t)];
+            const auto &halo = tile_halo[size_t(t)];
+            const auto &tv = tile_verts[size_t(t)];
+            const int32_t st = S.next();
+            for (int32_t i = 0; i < d.n_verts; ++i) {
+                S.vert_stamp[tv[size_t(i)]] = st;
+                S.vert_local[tv[size_t(i)]] = i;
+                P.gvid[size_t(d.vert_off) + size_t(i)] = tv[size_t(i)];
+            }
+            const int32_t nq = d.s_pad / 4;
+            auto slot_of_item = [&](int32_t L) { return balance ? 4 * (L % nq) + L / nq : L; };
+            auto item_tet = [&](int32_t L) { return L < d.n_owned ? own[size_t(L)] : halo[size_t(L - d.n_owned)]; };
+            for (int32_t L = 0; L < d.n_slots; ++L) {
+                int32_t el = item_tet(L);
+                S.tet_stamp[el] = st + (L < d.n_owned ? 0 : 1);
+                S.tet_slot[el] = slot_of_item(L);
+            }
+            uint32_t *pl = P.blob.data() + d.blob_off / 4;
+            const uint32_t ZS = uint32_t(d.s_pad);
+            // padding defaults: lv = 0, nbr = zero slot, dminv = 0
+            for (int32_t s = 0; s < d.s_pad; ++s) {
+                pl[2 * size_t(d.s_pad) + s] = ZS | (ZS << 16);
+                pl[3 * size_t(d.s_pad) + s] = ZS | (ZS << 16);
+            }
+            int32_t *stet = P.slot_tet.data() + P.slot_base[size_t(t)];
+            for (int32_t L = 0; L < d.n_slots; ++L) {
+                const int32_t el = item_tet(L);
+                const int32_t s = slot_of_item(L);
+                const bool owned = L < d.n_owned;
+                stet[s] = el;
+                uint32_t lv[4], nb[4];
+                for (int a = 0; a < 4; ++a) lv[a] = uint32_t(S.vert_local[tets[4 * int64_t(el) + a]]);
+                if (owned) lv[0] |= kOwnedBit;
+                for (int k = 0; k < 4; ++k) {
+                    int32_t q = P.nbr[4 * size_t(el) + k];
+                    uint32_t v = ZS;
+                    if (q >= 0) {
+                        int32_t qs = S.tet_stamp[q];
+                        if (owned) {
+                            v = uint32_t(S.tet_slot[q]);  // by construction q is owned or halo here
+                        } else if (qs == st) {
+                            v = uint32_t(S.tet_slot[q]);  // halo tets only look at owned neighbours
+                        }
+                    }
+                    nb[k] = v;
+                }
+                pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
+                pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
+                pl[2 * size_t(d.s_pad) + s] = nb[0] | (owned ? kOwnedBit : 0u) | (nb[1] << 16);
+                pl[3 * size_t(d.s_pad) + s] = nb[2] | (nb[3] << 16);
+                // Dm^-1 in double from the fp32 rest positions, rounded to fp32
+                const int32_t *tt = tets + 4 * int64_t(el);
+                double D[9];
+                for (int i = 0; i < 3; ++i)
+                    for (int k = 0; k < 3; ++k)
+                        D[3 * i + k] = double(rest[3 * size_t(tt[k + 1]) + i]) - double(rest[3 * size_t(tt[0]) + i]);
+                double Cf[9];
+                Cf[0] = D[4] * D[8] - D[5] * D[7];
+                Cf[1] = D[5] * D[6] - D[3] * D[8];
+                Cf[2] = D[3] * D[7] - D[4] * D[6];
+                Cf[3] = D[2] * D[7] - D[1] * D[8];
+                Cf[4] = D[0] * D[8] - D[2] * D[6];
+                Cf[5] = D[1] * D[6] - D[0] * D[7];
+                Cf[6] = D[1] * D[5] - D[2] * D[4];
+                Cf[7] = D[2] * D[3] - D[0] * D[5];
+                Cf[8] = D[0] * D[4] - D[1] * D[3];
+                const double det = D[0] * Cf[0] + D[1] * Cf[1] + D[2] * Cf[2];
+                if (det == 0.0 || !std::isfinite(det)) {
+                    singular.store(1);
+                    continue;
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int k = 0; k < 3; ++k) {
+                        float v = float(Cf[3 * k + i] / det);  // inverse = cofactor^T / det
+                        std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
+                    }
+            }
+        }
+    });
+    if (singular.load()) {
+        err = "singular (zero-volume) rest tetrahedron";
+        return ERR_BAD_MESH;
+    }
+
+    // ---- finish lists: every vertex not owned by exactly one tile ----
+    {
+        std::vector<int32_t> fin_of(static_cast<size_t>(n), -1);
+        int64_t entries = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            int32_t c = vcount[size_t(v)].load(std::memory_order_relaxed);
+            if (c == 1) continue;
+            fin_of[size_t(v)] = int32_t(P.fin_vid.size());
+            P.fin_vid.push_back(int32_t(v));
+            P.fin_off.push_back(int32_t(entries));
+            entries += c;
+            if (entries >= (int64_t(1) << 31)) {
+                err = "too many shared vertex copies for 32-bit offsets";
+                return ERR_TILING;
+            }
+        }
+        P.fin_off.push_back(int32_t(entries));
+        P.fin_idx.assign(size_t(entries), 0);
+        std::vector<int32_t> cur(P.fin_off.begin(), P.fin_off.end() - 1);
+        for (int64_t t = 0; t < T; ++t) {
+            const TileDesc &d = P.tiles[size_t(t)];
+            for (int32_t i = d.n_excl; i < d.n_verts; ++i) {
+                int32_t v = P.gvid[size_t(d.vert_off) + size_t(i)];
+                int32_t k = fin_of[size_t(v)];
+                P.fin_idx[size_t(cur[size_t(k)]++)] = int32_t(d.stage_off + (i - d.n_excl));
+            }
+        }
+    }
+    return OK;
+}
+
+int read_veg(const char *path, std::vector<float> &rest, std::vector<int32_t> &tets, std::string &err)
+{
+    std::ifstream in(path);
+    if (!in) {
+        err = std::string("cannot open ") + (path ? path : "(null)");
+        return ERR_IO;
+    }
+    rest.clear();
+    tets.clear();
+    std::vector<int64_t> ids;
+    std::string line;
+    int mode = 0, header = 0;  // 1 = vertices, 2 = elements
+    int64_t min_id = std::numeric_limits<int64_t>::max();
+    while (std::getline(in, line)) {
+        size_t p = line.find_first_not_of(" \t\r\n");
+        if (p == std::string::npos || line[p] == '#') continue;
+        if (line[p] == '*') {
+            std::string key = line.substr(p);
+            for (auto &ch : key) ch = char(std::toupper(static_cast<unsigned char>(ch)));
+            if (key.rfind("*VERTICES", 0) == 0) {
+                mode = 1;
+                header = 1;
+            } else if (key.rfind("*ELEMENTS", 0) == 0) {
+                mode = 2;
+                header = 2;
+            } else {
+                mode = 0;
+            }
+            continue;
+        }
+        if (!mode) continue;
+        if (header) {
+            --header;
+            if (mode == 2 && header == 1) {
+                std::string ty = line.substr(p);
+                while (!ty.empty() && std::isspace(static_cast<unsigned char>(ty.back()))) ty.pop_back();
+                if (ty != "TET" && ty != "TETS") {
+                    err = "only TET elements are supported, got '" + ty + "'";
+                    return ERR_IO;
+                }
+            }
+            continue;
+        }
+        for (auto &ch : line)
+            if (ch == ',') ch = ' ';
+        std::istringstream ss(line);
+        if (mode == 1) {
+            int64_t id;
+            double x, y, z;
+            if (!(ss >> id >> x >> y >> z)) {
+                err = "malformed vertex line: " + line;
+                return ERR_IO;
+            }
+            min_id = std::min(min_id, id);
+            rest.push_back(float(x));
+            rest.push_back(float(y));
+            rest.push_back(float(z));
+        } else {
+            int64_t id, a, b, c, d;
+            if (!(ss >> id >> a >> b >> c >> d)) {
+                err = "malformed element line: " + line;
+                return ERR_IO;
+            }
+            ids.insert(ids.end(), {a, b, c, d});
+        }
+    }
+    if (rest.empty() || ids.empty()) {
+        err = "no vertices or no tet elements found";
+        return ERR_IO;
+    }
+    const int64_t base = min_id == std::numeric_limits<int64_t>::max() ? 1 : min_id;
+    tets.resize(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) tets[i] = int32_t(ids[i] - base);
+    return OK;
+}
+
+}  // namespace tsamd

@@ -1,0 +1,72 @@
+// Host-side tiling plan for the fused tet-energy kernels (no HIP in this header).
+//
+// The reference builds two global sparse matrices on the CPU at construction
+// (libpgo, /root/reference/tssplat_ext/tet_spheres/tet_spheres.cpp:140-159) and
+// streams ~2 KB/tet of COO data through five SpMVs per evaluation.  We instead
+// cut the tet mesh into LDS-sized *tiles* once, and per evaluation stream 52 B
+// per tile slot exactly once; everything else (F, L F, L^T L F, the vertex
+// accumulation) lives in LDS and registers.  See DESIGN.md.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tsamd {
+
+struct PlanOptions {
+    int lds_budget = 160 * 1024;  // bytes of LDS one workgroup may use
+    int max_threads = 1024;       // workgroup size cap (multiple of 64)
+    int target_owned = 0;         // 0 = auto
+    int balance = 1;              // interleave owned / halo slots over lanes
+    int num_threads = 0;          // 0 = hardware concurrency
+};
+
+// Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
+struct TileDesc {
+    uint64_t blob_off;   // byte offset of the tile's 13 dword planes in the blob
+    int32_t n_slots;     // owned + halo tets
+    int32_t n_owned;
+    int32_t s_pad;       // n_slots rounded up to a multiple of 4 (= plane length in dwords)
+    int32_t n_verts;     // local vertices
+    int32_t n_excl;      // the first n_excl local vertices belong to this tile alone
+    int32_t vert_off;    // offset into gvid[]
+    int64_t stage_off;   // row offset into the staging buffer for the shared vertices
+    int32_t reserved[2];
+};
+static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI");
+
+constexpr int kPlanes = 13;          // lv01, lv23, nb01, nb23, dminv[9]
+constexpr uint32_t kOwnedBit = 0x8000u;
+
+// LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices.
+inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts)
+{
+    const int64_t sa = s_pad + 4;                 // + the all-zero slot, kept 16 B aligned
+    const int64_t vp = (n_verts + 3) & ~int64_t(3);
+    return 36 * sa + 16 * vp + 12 * vp + 256;     // F planes, x (float4), grad accumulators, reduction scratch
+}
+
+struct Plan {
+    int64_t n = 0, m = 0;
+    int64_t n_components = 0;
+    std::vector<int32_t> nbr;        // 4 per tet, -1 = boundary
+    std::vector<TileDesc> tiles;
+    std::vector<uint32_t> blob;      // all tiles' planes
+    std::vector<int32_t> gvid;       // all tiles' local->global vertex ids
+    std::vector<int32_t> slot_tet;   // per tile s_pad entries, global tet id or -1 (host only)
+    std::vector<int64_t> slot_base;  // per tile offset into slot_tet
+    std::vector<int32_t> fin_vid, fin_off, fin_idx;
+    int64_t n_stage = 0;             // rows in the staging buffer
+    int64_t total_slots = 0, total_tile_verts = 0;
+    int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0;
+};
+
+// Returns 0 on success, otherwise a tsamd_status value with `err` filled in.
+int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt,
+               Plan &plan, std::string &err);
+
+// Minimal Vega .veg reader (*VERTICES / *ELEMENTS TET), 0-based output.
+int read_veg(const char *path, std::vector<float> &rest, std::vector<int32_t> &tets, std::string &err);
+
+}  // namespace tsamd

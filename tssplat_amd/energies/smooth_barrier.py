@@ -1,0 +1,66 @@
+"""Host-side mirror of /root/reference/energies/smooth_barrier.py (:9-67).
+
+Same class names, constructor arguments, schedule and order switch, so a
+trainer written against the reference's ``energies.smooth_barrier`` runs on
+the MI355X kernels by changing one import.  The only dependency dropped is the
+module-level ``import pypgo`` (smooth_barrier.py:1), which the reference file
+never uses.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .. import tet_spheres_ext
+
+__all__ = ["SmoothnessBarrierFunc", "SmoothnessBarrierEnergy"]
+
+
+class SmoothnessBarrierFunc(torch.autograd.Function):
+    """autograd bridge: saves ``x`` only, constants ride on ctx (smooth_barrier.py:9-31)."""
+
+    @staticmethod
+    def forward(x_cur, tet_sp, c1, c2, order):
+        return tet_spheres_ext.forward(x_cur, tet_sp, c1, c2, order)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        x_cur, tet_sp, c1, c2, order = inputs
+        ctx.save_for_backward(x_cur)
+        ctx.constants = (tet_sp, c1, c2, order)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None, None, None, None
+        (x_cur,) = ctx.saved_tensors
+        tet_sp, c1, c2, order = ctx.constants
+        grad_final = tet_spheres_ext.backward(grad_output, x_cur, tet_sp, c1, c2, int(order))
+        return grad_final, None, None, None, None
+
+
+class SmoothnessBarrierEnergy(torch.nn.Module):
+    """Builds the device state from the rest mesh and evaluates the scheduled energy
+    (smooth_barrier.py:34-67).  ``FLAGS`` needs ``smooth_eng_coeff``, ``barrier_coeff`` and
+    ``increase_order_iter`` (config/gso.yaml:8-11)."""
+
+    def __init__(self, tet_v, tet_f, FLAGS, **tet_spheres_kwargs) -> None:
+        super().__init__()
+        v_flat = np.asarray(tet_v).flatten().astype(np.float32)      # smooth_barrier.py:38
+        f_flat = np.asarray(tet_f).flatten().astype(np.int32)        # smooth_barrier.py:39
+        self.tet_sp = tet_spheres_ext.TetSpheres(v_flat, f_flat, **tet_spheres_kwargs)
+        self.FLAGS = FLAGS
+        self.smooth_eng_func = SmoothnessBarrierFunc()
+
+    def coeff_scheduler(self, it):
+        """x1 at it=0 rising to x16 from it=1200 on (smooth_barrier.py:47-58)."""
+        smooth_coeff = self.FLAGS.smooth_eng_coeff
+        barrier_coeff = self.FLAGS.barrier_coeff
+        multiplier = math.pow(2, abs(math.sin(min(it / 300.0 / 4 * 0.5 * math.pi, 0.5 * math.pi))) * 4)
+        return smooth_coeff * multiplier, barrier_coeff * multiplier
+
+    def forward(self, x, it, c1, c2):
+        order = 4 if it > self.FLAGS.increase_order_iter else 2      # smooth_barrier.py:61-63
+        return self.smooth_eng_func.apply(x, self.tet_sp, c1, c2, order)
