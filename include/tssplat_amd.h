@@ -131,6 +131,15 @@ int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *gra
 /* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 
+/*
+ * Kernel timing for bench.py's roofline leg.  While enabled, every evaluation records HIP
+ * events on its stream around the tile kernel and the finish kernel (no host sync).
+ * tsamd_get_timing synchronises those events, returns the accumulated milliseconds and the
+ * number of evaluations, and clears the record.
+ */
+int tsamd_set_timing(tsamd_handle *h, int enable);
+int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_kernel_ms, int64_t *evaluations);
+
 /* out[i] = in[i] * (*scalar_dev); in == out allowed. */
 int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream);
 /*

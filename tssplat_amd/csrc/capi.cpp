@@ -71,6 +71,9 @@ struct tsamd_handle {
     double *d_partials = nullptr;
     double *d_terms = nullptr;
     float *d_energy_scratch = nullptr;
+    // optional kernel timing (bench.py roofline leg)
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
 
 namespace {
@@ -101,6 +104,7 @@ void release(tsamd_handle *h)
         (void)hipFree(h->d_partials);
         (void)hipFree(h->d_terms);
         (void)hipFree(h->d_energy_scratch);
+        for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     }
     delete h;
 }
@@ -221,7 +225,14 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.partials = h->d_partials;
     a.energy = energy;
     a.terms = h->d_terms;
-    TSAMD_HIP(tsamd::launch_eval(a, static_cast<hipStream_t>(stream)));
+    if (h->timing) {
+        hipEvent_t ev[3];
+        for (auto &e : ev) TSAMD_HIP(hipEventCreate(&e));
+        h->events.insert(h->events.end(), ev, ev + 3);
+        TSAMD_HIP(tsamd::launch_eval(a, static_cast<hipStream_t>(stream), ev));
+    } else {
+        TSAMD_HIP(tsamd::launch_eval(a, static_cast<hipStream_t>(stream)));
+    }
     return TSAMD_OK;
 }
 
@@ -342,6 +353,38 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
     TSAMD_HIP(hipMemcpyAsync(terms_host2, h->d_terms, 2 * sizeof(double), hipMemcpyDeviceToHost,
                              static_cast<hipStream_t>(stream)));
     TSAMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_set_timing(tsamd_handle *h, int enable)
+{
+    if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "handle is null");
+    if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
+    h->timing = enable != 0;
+    return TSAMD_OK;
+}
+
+int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_kernel_ms, int64_t *evaluations)
+{
+    if (!h || !tile_kernel_ms || !finish_kernel_ms || !evaluations) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    double a = 0.0, b = 0.0;
+    const size_t n = h->events.size() / 3;
+    for (size_t i = 0; i < n; ++i) {
+        hipEvent_t *ev = &h->events[3 * i];
+        TSAMD_HIP(hipEventSynchronize(ev[2]));
+        float m0 = 0.f, m1 = 0.f;
+        TSAMD_HIP(hipEventElapsedTime(&m0, ev[0], ev[1]));
+        TSAMD_HIP(hipEventElapsedTime(&m1, ev[1], ev[2]));
+        a += m0;
+        b += m1;
+    }
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    h->events.clear();
+    *tile_kernel_ms = a;
+    *finish_kernel_ms = b;
+    *evaluations = int64_t(n);
     return TSAMD_OK;
 }
 

@@ -29,7 +29,8 @@ struct EvalArgs {
     double *terms;          // [2] (E_s, E_b), always written when energy != nullptr
 };
 
-hipError_t launch_eval(const EvalArgs &a, hipStream_t stream);
+// ev: optional 3 events recorded before the tile kernel, between the two kernels, after the finish kernel
+hipError_t launch_eval(const EvalArgs &a, hipStream_t stream, hipEvent_t *ev = nullptr);
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
 hipError_t configure_kernels(int lds_bytes);

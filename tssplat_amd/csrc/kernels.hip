@@ -432,6 +432,8 @@ int grid_for(int64_t n, int per_block, int cap)
 
 }  // namespace
 
+hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev);
+
 hipError_t configure_kernels(int lds_bytes)
 {
     const void *fns[4] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024>),
@@ -445,7 +447,18 @@ hipError_t configure_kernels(int lds_bytes)
     return hipSuccess;
 }
 
-hipError_t launch_eval(const EvalArgs &e, hipStream_t stream)
+hipError_t launch_eval(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev)
+{
+    if (ev) {
+        hipError_t err = hipEventRecord(ev[0], stream);
+        if (err != hipSuccess) return err;
+    }
+    hipError_t rc = launch_eval_kernels(e, stream, ev);
+    if (rc == hipSuccess && ev) rc = hipEventRecord(ev[2], stream);
+    return rc;
+}
+
+hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev)
 {
     if (e.n_tiles > 0) {
         KernelArgs k;
@@ -473,6 +486,10 @@ hipError_t launch_eval(const EvalArgs &e, hipStream_t stream)
         else
             hipLaunchKernelGGL((tile_energy_kernel<false, 1024>), grid, block, size_t(e.lds_bytes), stream, k);
         hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    if (ev) {
+        hipError_t err = hipEventRecord(ev[1], stream);
         if (err != hipSuccess) return err;
     }
     FinishArgs f;

@@ -133,6 +133,16 @@ class TetSpheres:
         _capi.check(_lib.tsamd_get_plan_info(self._handle(), C.byref(info)))
         return info.as_dict()
 
+    def set_timing(self, enable: bool) -> None:
+        """Record HIP events around the kernels of every evaluation (bench.py roofline leg)."""
+        _capi.check(_lib.tsamd_set_timing(self._handle(), int(enable)))
+
+    def get_timing(self) -> tuple[float, float, int]:
+        """(tile kernel ms, finish kernel ms, evaluations) since the last call; blocks the host."""
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        _capi.check(_lib.tsamd_get_timing(self._handle(), C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def energy_terms(self) -> tuple[float, float]:
         """(E_s, E_b) of the last evaluation, in double.  Blocks the host."""
         out = (C.c_double * 2)()
