@@ -95,8 +95,10 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from tssplat_amd import scenes
-    from tssplat_amd.energies import SmoothnessBarrierEnergy
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the module prints "initializing" like the reference does
+        from tssplat_amd import scenes
+        from tssplat_amd.energies import SmoothnessBarrierEnergy
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +174,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    e_val = float(e)
+    e_val = float(e.detach())
 
     # ---- roofline leg: the tile kernel alone, HIP events on the launch stream ----
     energy.tet_sp.set_timing(True)

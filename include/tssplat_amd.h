@@ -140,6 +140,10 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 int tsamd_set_timing(tsamd_handle *h, int enable);
 int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_kernel_ms, int64_t *evaluations);
 
+/* Diagnostic only (tools/ablate.py): switch parts of the tile kernel off to price them.
+ * Any nonzero value makes results WRONG; production code never calls this. */
+int tsamd_debug_set_ablation(tsamd_handle *h, int flags);
+
 /* out[i] = in[i] * (*scalar_dev); in == out allowed. */
 int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream);
 /*

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Price the stages of the tile kernel by switching them off (results are wrong while a switch is on).
+
+    python tools/ablate.py [--scene kuhn19 --spheres 64] [--max-threads 768] ...
+
+Prints ms per evaluation (HIP events around the tile kernel) for each ablation mask.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+MASKS = [
+    (0, "full kernel"),
+    (1, "plain LDS stores instead of atomics"),
+    (2, "pass-3 gathers read own slot (no bank conflicts)"),
+    (4, "pass-2 gathers read own slot"),
+    (6, "both gather passes local"),
+    (7, "local gathers + plain stores"),
+    (8, "skip pass 3"),
+    (24, "skip passes 2 and 3"),
+    (32, "exit after pass 1"),
+    (64, "exit after loads (stream only)"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="kuhn19")
+    ap.add_argument("--spheres", type=int, default=64)
+    ap.add_argument("--sigma", type=float, default=0.02)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--max-threads", type=int, default=0)
+    ap.add_argument("--lds-budget", type=int, default=0)
+    ap.add_argument("--target-owned", type=int, default=0)
+    ap.add_argument("--no-balance", action="store_true")
+    ap.add_argument("--masks", default="")
+    args = ap.parse_args()
+    import torch
+    from tssplat_amd import _capi, scenes, tet_spheres_ext as T
+    lib = _capi.load()
+    sc = scenes.make_scene(args.scene, args.spheres)
+    ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), max_threads=args.max_threads,
+                      lds_budget_bytes=args.lds_budget, target_owned=args.target_owned,
+                      balance_slots=not args.no_balance)
+    info = ts.plan_info()
+    x = torch.from_numpy(scenes.deform(sc, args.sigma)).cuda()
+    g = torch.empty_like(x)
+    e = torch.empty((), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    masks = MASKS if not args.masks else [(int(m), "custom") for m in args.masks.split(",")]
+    out = {"scene": f"{args.spheres} x {args.scene}", "m": sc.n_tets, "n": sc.n_vertices, "plan": info, "rows": []}
+    for mask, what in masks:
+        _capi.check(lib.tsamd_debug_set_ablation(ts._handle(), mask))
+        for _ in range(3):
+            _capi.check(lib.tsamd_forward_backward(ts._handle(), x.data_ptr(), None, 1e-4, 2e-4, 2, stream,
+                                                   e.data_ptr(), g.data_ptr()))
+        ts.set_timing(True)
+        for _ in range(args.reps):
+            _capi.check(lib.tsamd_forward_backward(ts._handle(), x.data_ptr(), None, 1e-4, 2e-4, 2, stream,
+                                                   e.data_ptr(), g.data_ptr()))
+        tile_ms, fin_ms, n = ts.get_timing()
+        ts.set_timing(False)
+        row = {"mask": mask, "what": what, "tile_ms": tile_ms / n, "finish_ms": fin_ms / n,
+               "gtets_per_s": sc.n_tets / (tile_ms / n * 1e-3) / 1e9}
+        out["rows"].append(row)
+        print(f"mask {mask:3d} {what:50s} tile {row['tile_ms']:.4f} ms  finish {row['finish_ms']:.4f} ms  "
+              f"{row['gtets_per_s']:.2f} Gtet/s", flush=True)
+    _capi.check(lib.tsamd_debug_set_ablation(ts._handle(), 0))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

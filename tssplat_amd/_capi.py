@@ -77,6 +77,7 @@ SIGNATURES = {
     "tsamd_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "tsamd_debug_set_ablation": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -94,6 +95,10 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # The host framework's HIP runtime must be in the process first: torch bundles its own
+    # libamdhip64.so.7, and a second copy (from /opt/rocm) loaded ahead of it leaves one of the
+    # two runtimes without devices ("no HIP device is visible").
+    import torch  # noqa: F401
     path = _build.LIB
     if build_if_missing:
         try:

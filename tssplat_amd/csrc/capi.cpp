@@ -72,6 +72,7 @@ struct tsamd_handle {
     double *d_terms = nullptr;
     float *d_energy_scratch = nullptr;
     // optional kernel timing (bench.py roofline leg)
+    int dbg = 0;  // kernel ablation switches, tools/ablate.py only
     bool timing = false;
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
@@ -215,6 +216,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.n_finish = int64_t(h->plan.fin_vid.size());
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
+    a.dbg = h->dbg;
     a.x = x;
     a.grad_out = grad_out;
     a.c1 = c1;
@@ -353,6 +355,13 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
     TSAMD_HIP(hipMemcpyAsync(terms_host2, h->d_terms, 2 * sizeof(double), hipMemcpyDeviceToHost,
                              static_cast<hipStream_t>(stream)));
     TSAMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_debug_set_ablation(tsamd_handle *h, int flags)
+{
+    if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "handle is null");
+    h->dbg = flags;
     return TSAMD_OK;
 }
 

@@ -17,6 +17,7 @@ struct EvalArgs {
     const int32_t *fin_vid, *fin_off, *fin_idx;
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
+    int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
     // per evaluation
     const float *x;
     const float *grad_out;  // device scalar or nullptr

@@ -90,7 +90,11 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
+    int dbg;  // ablation switches for tools/ablate.py (0 in production)
 };
+
+enum : int { DBG_PLAIN_STORE = 1, DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
+             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64 };
 
 // BLOCK is the largest workgroup the instantiation may be launched with; it only sets the VGPR
 // budget (1024 threads = 4 waves/SIMD = 128 VGPRs, 768 = 3 waves/SIMD = 168 VGPRs).
@@ -148,6 +152,11 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         FC[ZS] = 0.f;
     }
     __syncthreads();
+    if (a.dbg & DBG_EXIT_AFTER_LOAD) {
+        float chk = dm[0].x + dm[4].y + dm[8].z + float(q_lv01.x ^ q_lv23.y ^ q_nb01.z ^ q_nb23.w) + xs[tid % td.n_verts].x;
+        if (chk == 12345.678f) a.partials[0] = chk;
+        return;
+    }
 
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
     float scal[4] = {0.f, 0.f, 0.f, 0.f};  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
@@ -183,17 +192,22 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         reinterpret_cast<float4 *>(FC)[tid] = make_float4(f8[0], f8[1], f8[2], f8[3]);
     }
     __syncthreads();
+    if (a.dbg & DBG_EXIT_AFTER_P1) {
+        if (e_b == 12345.678f) a.partials[0] = e_b;
+        return;
+    }
 
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
     float H[4][9];
-    if (active) {
+    if (active && !(a.dbg & DBG_SKIP_P2)) {
         const float4 own8 = reinterpret_cast<const float4 *>(FC)[tid];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
             const bool owned = (n01 & kOwnedBit) != 0;
-            const uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
+            uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
             const int s = 4 * tid + p;
+            if (a.dbg & DBG_LOCAL_GATHER2) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(s);
             const float4 fa = FA[s], fb = FB[s];
             const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
             float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
@@ -240,14 +254,15 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         __syncthreads();
 
         // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  scatter P Dm^-T to the tile's vertices ----
-        if (active) {
+        if (active && !(a.dbg & DBG_SKIP_P3)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
                 const uint32_t lv[4] = {w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
                 const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
-                const uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
+                uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
                 const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
+                if (a.dbg & DBG_LOCAL_GATHER3) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(4 * tid + p);
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
                 const int so = 4 * tid + p;
                 const float4 ha = FA[so], hb = FB[so];
@@ -278,10 +293,12 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                     for (int k = 0; k < 3; ++k) {
                         const float d = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
                                         P[3 * i + 2] * comp(dm[3 * k + 2], p);
-                        atomicAdd(&gs[3 * lv[k + 1] + i], d);
+                        if (a.dbg & DBG_PLAIN_STORE) gs[3 * lv[k + 1] + i] = d;
+                        else atomicAdd(&gs[3 * lv[k + 1] + i], d);
                         tot += d;
                     }
-                    atomicAdd(&gs[3 * lv[0] + i], -tot);
+                    if (a.dbg & DBG_PLAIN_STORE) gs[3 * lv[0] + i] = -tot;
+                    else atomicAdd(&gs[3 * lv[0] + i], -tot);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -475,6 +492,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.order = e.order;
         k.n_tiles = int(e.n_tiles);
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
+        k.dbg = e.dbg;
         const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
         const bool small = e.block_threads <= 768;
         if (e.grad && small)
