@@ -62,6 +62,7 @@ typedef struct tsamd_options {
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
+    int32_t debug_shuffle;     /* experiment: spread a tile's tets over lanes instead of Morton order */
 } tsamd_options;
 
 /* Introspection of the tiling plan (host side; valid for host_only handles too). */
@@ -82,7 +83,10 @@ typedef struct tsamd_plan_info {
 typedef struct tsamd_tile_view {
     int32_t n_slots, n_owned, s_pad, n_verts, n_excl;
     int64_t stage_off;
+    int32_t n_inc4;           /* incidence list length in 4-entry chunks                           */
     const uint32_t *planes;   /* 13 planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]   */
+    const uint16_t *inc;      /* 4*n_inc4 entries (slot << 2 | a), grouped by local vertex          */
+    const uint16_t *inc_off;  /* n_verts + 1 chunk offsets                                          */
     const int32_t *gvid;      /* n_verts global vertex ids, exclusive ones first                    */
     const int32_t *slot_tet;  /* s_pad global tet ids (-1 = padding)                                */
 } tsamd_tile_view;

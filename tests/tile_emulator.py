@@ -27,10 +27,12 @@ def plan_tiles(ts):
         _capi.check(lib.tsamd_get_tile(ts._handle(), t, C.byref(tv)))
         sp = tv.s_pad
         planes = np.ctypeslib.as_array(tv.planes, shape=(13, sp)).copy()
+        inc = np.ctypeslib.as_array(tv.inc, shape=(max(4 * tv.n_inc4, 1),)).copy()[:4 * tv.n_inc4]
+        inc_off = np.ctypeslib.as_array(tv.inc_off, shape=(tv.n_verts + 1,)).copy()
         gvid = np.ctypeslib.as_array(tv.gvid, shape=(tv.n_verts,)).copy()
         slot_tet = np.ctypeslib.as_array(tv.slot_tet, shape=(sp,)).copy()
         yield dict(n_slots=tv.n_slots, n_owned=tv.n_owned, s_pad=sp, n_verts=tv.n_verts, n_excl=tv.n_excl,
-                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet)
+                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet, inc=inc, inc_off=inc_off)
 
 
 def finish_lists(ts):
@@ -120,10 +122,21 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         Q = deg[:, None] * Hz[:sp] - Hz[nb].sum(axis=1)
         P = c1 * Q.reshape(sp, 3, 3) + scal[:, None, None] * _cof(F)
         d = P @ np.transpose(dminv, (0, 2, 1))
+        # per-vertex gather through the incidence lists, exactly as the kernel's last phase does
+        dz = np.concatenate([d, np.zeros((1, 3, 3))], axis=0)                   # + zero slot
+        contrib = np.concatenate([-dz.sum(axis=2)[:, None, :], np.transpose(dz, (0, 2, 1))], axis=1)  # [slot, a, xyz]
+        inc, inc_off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
+        assert inc_off[0] == 0 and inc_off[-1] * 4 == len(inc) and np.all(np.diff(inc_off) >= 0)
+        sl, la = inc >> 2, inc & 3
+        real = sl != ZS
+        assert np.all(la[~real] == 1)
+        # every (slot, a) of a real slot appears exactly once, under the right vertex
+        owner = np.repeat(np.arange(T["n_verts"]), 4 * np.diff(inc_off))
+        assert np.array_equal(lv[sl[real], la[real]], owner[real])
+        assert real.sum() == 4 * T["n_slots"]
+        assert len(np.unique(inc[real])) == real.sum()
         gs = np.zeros((T["n_verts"], 3))
-        for k in range(3):
-            np.add.at(gs, lv[:, k + 1], d[:, :, k])
-        np.add.at(gs, lv[:, 0], -d.sum(axis=2))
+        np.add.at(gs, owner, contrib[sl, la])
         ne = T["n_excl"]
         assert np.all(np.isnan(grad[T["gvid"][:ne]])), "an exclusive vertex was written twice"
         grad[T["gvid"][:ne]] = gs[:ne] * grad_output

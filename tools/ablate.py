@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--target-owned", type=int, default=0)
     ap.add_argument("--no-balance", action="store_true")
     ap.add_argument("--masks", default="")
+    ap.add_argument("--shuffle", action="store_true")
     args = ap.parse_args()
     import torch
     from tssplat_amd import _capi, scenes, tet_spheres_ext as T
@@ -44,7 +45,7 @@ def main():
     sc = scenes.make_scene(args.scene, args.spheres)
     ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), max_threads=args.max_threads,
                       lds_budget_bytes=args.lds_budget, target_owned=args.target_owned,
-                      balance_slots=not args.no_balance)
+                      balance_slots=not args.no_balance, debug_shuffle=args.shuffle)
     info = ts.plan_info()
     x = torch.from_numpy(scenes.deform(sc, args.sigma)).cuda()
     g = torch.empty_like(x)

@@ -33,6 +33,7 @@ class Options(C.Structure):
         ("balance_slots", C.c_int32),
         ("host_only", C.c_int32),
         ("num_threads", C.c_int32),
+        ("debug_shuffle", C.c_int32),
     ]
 
 
@@ -52,8 +53,9 @@ class PlanInfo(C.Structure):
 class TileView(C.Structure):
     _fields_ = [
         ("n_slots", C.c_int32), ("n_owned", C.c_int32), ("s_pad", C.c_int32), ("n_verts", C.c_int32),
-        ("n_excl", C.c_int32), ("stage_off", C.c_int64),
-        ("planes", C.POINTER(C.c_uint32)), ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)),
+        ("n_excl", C.c_int32), ("stage_off", C.c_int64), ("n_inc4", C.c_int32),
+        ("planes", C.POINTER(C.c_uint32)), ("inc", C.POINTER(C.c_uint16)), ("inc_off", C.POINTER(C.c_uint16)),
+        ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)),
     ]
 
 

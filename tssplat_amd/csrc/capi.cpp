@@ -163,6 +163,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.target_owned = opt.target_owned;
     po.balance = opt.balance_slots;
     po.num_threads = opt.num_threads;
+    po.shuffle = opt.debug_shuffle;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;
@@ -300,7 +301,10 @@ int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out)
     out->n_verts = d.n_verts;
     out->n_excl = d.n_excl;
     out->stage_off = d.stage_off;
+    out->n_inc4 = d.n_inc4;
     out->planes = P.blob.data() + d.blob_off / 4;
+    out->inc = reinterpret_cast<const uint16_t *>(out->planes + size_t(tsamd::kPlanes) * size_t(d.s_pad));
+    out->inc_off = out->inc + 4 * size_t(d.n_inc4);
     out->gvid = P.gvid.data() + d.vert_off;
     out->slot_tet = P.slot_tet.data() + P.slot_base[size_t(tile)];
     return TSAMD_OK;

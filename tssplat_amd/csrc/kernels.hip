@@ -12,7 +12,9 @@
 //   pass 1  F = Ds Dm^-1, det, penalty     <- cusparseSpMV(G,x) :167,:221 + cuda_forward_det :48-66
 //   pass 2  H = L F, 1/2|H|^2              <- cusparseSpMV(GTLTLG,x) :131 + cublasSdot :154 (factored, no M)
 //   pass 3  P = c1 L^T H + c2 dpen cof(F)  <- cusparseSpMV(GTLTLG,x) :216 + cuda_backward_det :68-102
-//           g += P Dm^-T (LDS atomics)     <- cusparseSpMV(TRANSPOSE, G) :248
+//           d = P Dm^-T, per-vertex gather <- cusparseSpMV(TRANSPOSE, G) :248 (their transposed COO SpMV
+//                                             scatters with atomics; LDS f32 atomics measured ~3 clk/lane
+//                                             on gfx950, so each vertex sums its incident tets instead)
 //   finish  sum shared-vertex partials, reduce energy, * grad_out
 //                                          <- cublasSasum :185, host combine :191, cublasSscal :258
 // There is no host synchronisation anywhere (the reference blocks three times
@@ -93,7 +95,7 @@ struct KernelArgs {
     int dbg;  // ablation switches for tools/ablate.py (0 in production)
 };
 
-enum : int { DBG_PLAIN_STORE = 1, DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
+enum : int { DBG_UNUSED1 = 1, DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
              DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64 };
 
 // BLOCK is the largest workgroup the instantiation may be launched with; it only sets the VGPR
@@ -121,8 +123,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     float4 *FB = FA + SA;
     float *FC = reinterpret_cast<float *>(FB + SA);
     float4 *xs = reinterpret_cast<float4 *>(FC + SA);
-    float *gs = reinterpret_cast<float *>(xs + VP);
-    double *red = reinterpret_cast<double *>(gs + 3 * VP);
+    double *red = reinterpret_cast<double *>(xs + VP);
 
     const bool active = tid < nq;
     const uint4 *pl = reinterpret_cast<const uint4 *>(a.blob + td.blob_off);
@@ -144,8 +145,6 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         const size_t gv = size_t(a.gvid[td.vert_off + v]) * 3;
         xs[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
     }
-    if (WITH_GRAD)
-        for (int i = tid; i < 3 * VP; i += nthr) gs[i] = 0.f;
     if (tid == 0) {
         FA[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
         FB[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,12 +252,13 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         }
         __syncthreads();
 
-        // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  scatter P Dm^-T to the tile's vertices ----
+        // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T (per-tet vertex forces) ----
+        // d[i][k] = sum_j P[i][j] Dminv[k][j] is the force on local vertex k+1; vertex 0 gets -(sum).
+        // Held in registers across the barrier, then written over H (all reads of H are done by then).
+        float D[4][9];
         if (active && !(a.dbg & DBG_SKIP_P3)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
-                const uint32_t lv[4] = {w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16};
                 const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
                 uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
                 const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
@@ -279,41 +279,69 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
                 for (int c = 0; c < 9; ++c) P[c] *= a.c1;
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
+                    const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
                     float F[9], C[9];
-                    slot_F(xs, lv[0], lv[1], lv[2], lv[3], dm, p, F);
+                    slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
                     cof3(F, C);
 #pragma unroll
                     for (int c = 0; c < 9; ++c) P[c] += scal[p] * C[c];
                 }
-                // dE/dDs = P Dm^-T : d[i][k] = sum_j P[i][j] Dminv[k][j]; column k -> vertex k+1
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    float tot = 0.f;
+                for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float d = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
-                                        P[3 * i + 2] * comp(dm[3 * k + 2], p);
-                        if (a.dbg & DBG_PLAIN_STORE) gs[3 * lv[k + 1] + i] = d;
-                        else atomicAdd(&gs[3 * lv[k + 1] + i], d);
-                        tot += d;
-                    }
-                    if (a.dbg & DBG_PLAIN_STORE) gs[3 * lv[0] + i] = -tot;
-                    else atomicAdd(&gs[3 * lv[0] + i], -tot);
-                }
+                    for (int i = 0; i < 3; ++i)
+                        D[p][3 * k + i] = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
+                                          P[3 * i + 2] * comp(dm[3 * k + 2], p);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int s = 4 * tid + p;
+                FA[s] = make_float4(D[p][0], D[p][1], D[p][2], D[p][3]);   // v1.xyz, v2.x
+                FB[s] = make_float4(D[p][4], D[p][5], D[p][6], D[p][7]);   // v2.yz, v3.xy
+            }
+            reinterpret_cast<float4 *>(FC)[tid] = make_float4(D[0][8], D[1][8], D[2][8], D[3][8]);  // v3.z
         }
         __syncthreads();
 
-        // ---- write out: exclusive vertices straight to grad, shared ones to the staging rows ----
+        // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
+        // Exclusive vertices go straight to grad, vertices shared with other tiles to the staging rows.
         const float gscale = a.grad_out ? *a.grad_out : 1.f;
-        const int n_ex3 = 3 * td.n_excl, n_all3 = 3 * td.n_verts;
-        for (int i = tid; i < n_ex3; i += nthr) {
-            const int v = i / 3, c = i - 3 * v;
-            a.grad[size_t(a.gvid[td.vert_off + v]) * 3 + c] = gs[i] * gscale;
+        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
+        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
+        for (int v = tid; v < td.n_verts; v += nthr) {
+            const int c0 = inc_off[v], c1 = inc_off[v + 1];
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            for (int c = c0; c < c1; ++c) {
+                const uint2 w = inc[c];
+                const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t sl = ent[q] >> 2, lc = ent[q] & 3u;
+                    const float4 da = FA[sl], db = FB[sl];
+                    const float dc = FC[sl];
+                    // a=1: (da.x da.y da.z)  a=2: (da.w db.x db.y)  a=3: (db.z db.w dc)  a=0: -(sum)
+                    const float sx = da.x + da.w + db.z, sy = da.y + db.x + db.w, sz = da.z + db.y + dc;
+                    gx += lc == 0 ? -sx : (lc == 1 ? da.x : (lc == 2 ? da.w : db.z));
+                    gy += lc == 0 ? -sy : (lc == 1 ? da.y : (lc == 2 ? db.x : db.w));
+                    gz += lc == 0 ? -sz : (lc == 1 ? da.z : (lc == 2 ? db.y : dc));
+                }
+            }
+            float *dst = v < td.n_excl ? a.grad + size_t(a.gvid[td.vert_off + v]) * 3
+                                       : a.stage + (size_t(td.stage_off) + size_t(v - td.n_excl)) * 3;
+            const float sc = v < td.n_excl ? gscale : 1.f;
+            dst[0] = gx * sc;
+            dst[1] = gy * sc;
+            dst[2] = gz * sc;
         }
-        float *st = a.stage + size_t(td.stage_off) * 3;
-        for (int i = n_ex3 + tid; i < n_all3; i += nthr) st[i - n_ex3] = gs[i];
     }
 
     // ---- deterministic block reduction of the two energy terms (fixed order, double) ----

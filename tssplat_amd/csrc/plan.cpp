@@ -308,7 +308,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 160 * 1024;
-    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 32764);  // slot ids share a halfword with the owned bit
+    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 16380);  // (slot << 2 | a) must fit 16 bits
     if (lim.budget < tile_lds_bytes(8, 8)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
@@ -454,6 +454,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
 
     // ---- pass A: per-tile halo + vertex lists, global per-vertex tile count ----
     std::vector<std::vector<int32_t>> tile_halo(static_cast<size_t>(T)), tile_verts(static_cast<size_t>(T));
+    std::vector<int32_t> tile_inc4(static_cast<size_t>(T), 0);
     std::vector<std::atomic<int32_t>> vcount(static_cast<size_t>(n));
     for (auto &a : vcount) a.store(0, std::memory_order_relaxed);
     parallel_chunks(T, 4, nthreads, [&](int64_t b, int64_t e, int w) {
@@ -477,6 +478,19 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             for (int32_t el : own) touch(el);
             for (int32_t el : tile_halo[size_t(t)]) touch(el);
             for (int32_t v : tv) vcount[size_t(v)].fetch_add(1, std::memory_order_relaxed);
+            // incidence chunks: every vertex's (slot, a) list is padded to a multiple of 4 entries
+            {
+                std::vector<int32_t> cnt(tv.size(), 0);
+                for (size_t i = 0; i < tv.size(); ++i) S.vert_local[tv[i]] = int32_t(i);
+                auto count = [&](int32_t el) {
+                    for (int a = 0; a < 4; ++a) ++cnt[size_t(S.vert_local[tets[4 * int64_t(el) + a]])];
+                };
+                for (int32_t el : own) count(el);
+                for (int32_t el : tile_halo[size_t(t)]) count(el);
+                int64_t chunks = 0;
+                for (int32_t c : cnt) chunks += (c + 3) / 4;
+                tile_inc4[size_t(t)] = int32_t(chunks);
+            }
         }
     });
 
@@ -502,7 +516,13 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         d.blob_off = uint64_t(blob_bytes);
         d.vert_off = int32_t(vert_off);
         d.stage_off = stage_off;
-        blob_bytes += (int64_t(kPlanes) * d.s_pad * 4 + 127) & ~int64_t(127);
+        d.n_inc4 = tile_inc4[size_t(t)];
+        if (d.n_inc4 > 65535) {
+            err = "tile incidence list too long for 16-bit chunk offsets";
+            return ERR_TILING;
+        }
+        blob_bytes += (int64_t(kPlanes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1) + 127) &
+                      ~int64_t(127);
         vert_off += d.n_verts;
         stage_off += d.n_verts - d.n_excl;
         P.slot_base[size_t(t)] = slot_off;
@@ -542,7 +562,17 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 P.gvid[size_t(d.vert_off) + size_t(i)] = tv[size_t(i)];
             }
             const int32_t nq = d.s_pad / 4;
-            auto slot_of_item = [&](int32_t L) { return balance ? 4 * (L % nq) + L / nq : L; };
+            // shuffle: item L -> item (L * stride) mod n_slots with an odd-ish stride coprime to n_slots, so
+            // that the lanes of one wave hold tets that are far apart (no shared vertices)
+            int64_t stride = 1;
+            if (opt.shuffle && d.n_slots > 2) {
+                stride = std::max<int64_t>(2, int64_t(0.6180339887 * d.n_slots));
+                while (std::gcd<int64_t>(stride, d.n_slots) != 1) ++stride;
+            }
+            auto slot_of_item = [&](int32_t L0) {
+                const int32_t L = opt.shuffle ? int32_t((int64_t(L0) * stride) % d.n_slots) : L0;
+                return balance ? 4 * (L % nq) + L / nq : L;
+            };
             auto item_tet = [&](int32_t L) { return L < d.n_owned ? own[size_t(L)] : halo[size_t(L - d.n_owned)]; };
             for (int32_t L = 0; L < d.n_slots; ++L) {
                 int32_t el = item_tet(L);
@@ -608,6 +638,33 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         float v = float(Cf[3 * k + i] / det);  // inverse = cofactor^T / det
                         std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
                     }
+            }
+            // vertex incidence lists (the gradient is gathered per vertex, in this fixed order)
+            {
+                uint16_t *inc = reinterpret_cast<uint16_t *>(pl + size_t(kPlanes) * size_t(d.s_pad));
+                uint16_t *inc_off = inc + 4 * size_t(d.n_inc4);
+                std::vector<int32_t> cnt(size_t(d.n_verts), 0);
+                for (int32_t sl = 0; sl < d.s_pad; ++sl) {
+                    if (stet[sl] < 0) continue;
+                    for (int a = 0; a < 4; ++a) ++cnt[size_t(S.vert_local[tets[4 * int64_t(stet[sl]) + a]])];
+                }
+                int32_t chunk = 0;
+                std::vector<int32_t> cur(size_t(d.n_verts), 0);
+                for (int32_t v = 0; v < d.n_verts; ++v) {
+                    inc_off[v] = uint16_t(chunk);
+                    cur[size_t(v)] = 4 * chunk;
+                    chunk += (cnt[size_t(v)] + 3) / 4;
+                }
+                inc_off[d.n_verts] = uint16_t(chunk);
+                const uint16_t pad = uint16_t((ZS << 2) | 1u);
+                for (int64_t i = 0; i < 4 * int64_t(d.n_inc4); ++i) inc[i] = pad;
+                for (int32_t sl = 0; sl < d.s_pad; ++sl) {  // slot-major fill => each list is sorted by slot
+                    if (stet[sl] < 0) continue;
+                    for (int a = 0; a < 4; ++a) {
+                        int32_t v = S.vert_local[tets[4 * int64_t(stet[sl]) + a]];
+                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(sl) << 2) | uint32_t(a));
+                    }
+                }
             }
         }
     });

@@ -20,6 +20,7 @@ struct PlanOptions {
     int target_owned = 0;         // 0 = auto
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
+    int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
@@ -32,11 +33,17 @@ struct TileDesc {
     int32_t n_excl;      // the first n_excl local vertices belong to this tile alone
     int32_t vert_off;    // offset into gvid[]
     int64_t stage_off;   // row offset into the staging buffer for the shared vertices
-    int32_t reserved[2];
+    int32_t n_inc4;      // vertex-incidence list length in 4-entry (8 B) chunks
+    int32_t reserved;
 };
 static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI");
 
-constexpr int kPlanes = 13;          // lv01, lv23, nb01, nb23, dminv[9]
+// Per tile, in this order, inside the blob:
+//   13 planes of s_pad dwords : lv01, lv23, nb01, nb23, dminv[9]        (tet-slot major, 52 B / slot)
+//   n_inc4 chunks of 4 x u16  : vertex incidence entries (slot << 2 | local vertex a), grouped by
+//                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
+//   n_verts + 1 x u16         : first chunk of every local vertex
+constexpr int kPlanes = 13;
 constexpr uint32_t kOwnedBit = 0x8000u;
 
 // LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices.
@@ -44,7 +51,7 @@ inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts)
 {
     const int64_t sa = s_pad + 4;                 // + the all-zero slot, kept 16 B aligned
     const int64_t vp = (n_verts + 3) & ~int64_t(3);
-    return 36 * sa + 16 * vp + 12 * vp + 256;     // F planes, x (float4), grad accumulators, reduction scratch
+    return 36 * sa + 16 * vp + 256;               // F / H / d planes, x (float4), reduction scratch
 }
 
 struct Plan {
