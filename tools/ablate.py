@@ -14,11 +14,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 MASKS = [
     (0, "full kernel"),
-    (1, "plain LDS stores instead of atomics"),
     (2, "pass-3 gathers read own slot (no bank conflicts)"),
     (4, "pass-2 gathers read own slot"),
     (6, "both gather passes local"),
-    (7, "local gathers + plain stores"),
+    (128, "skip the per-vertex gather loop (stores zeros)"),
+    (256, "skip the gradient/stage stores"),
+    (384, "skip vertex gather and stores"),
     (8, "skip pass 3"),
     (24, "skip passes 2 and 3"),
     (32, "exit after pass 1"),

@@ -23,7 +23,9 @@ SOURCES = ["plan.cpp", "capi.cpp", "kernels.hip"]
 HEADERS = ["plan.h", "kernels.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]
-DEVICE_FLAGS = [f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast"]
+# -fno-slp-vectorize: SLP packs the 3x3 algebra into v_pk_*_f32, which runs at the scalar-fp32 rate on
+# gfx950 but costs ~400 v_mov_b32 of operand shuffling and 9 spilled VGPRs in the tile kernel.
+DEVICE_FLAGS = [f"--offload-arch={ARCH}", "-ffp-contract=fast", "-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:

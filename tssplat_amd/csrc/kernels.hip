@@ -27,6 +27,7 @@ namespace tsamd {
 namespace {
 
 constexpr int kWave = 64;
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float det3(const float *F)
 {
@@ -68,7 +69,15 @@ __device__ __forceinline__ double wave_sum(double v)
 __device__ __forceinline__ void slot_F(const float4 *xs, uint32_t lv0, uint32_t lv1, uint32_t lv2, uint32_t lv3,
                                        const float4 *dm, int p, float *F)
 {
-    const float4 x0 = xs[lv0], x1 = xs[lv1], x2 = xs[lv2], x3 = xs[lv3];
+    // xs holds (x, y, z, 0); reading it as 4 x u32 keeps the compiler from narrowing the access to
+    // ds_read_b96, which costs 8 LDS cycles against 4 for ds_read_b128
+    const v4u r0 = reinterpret_cast<const v4u *>(xs)[lv0], r1 = reinterpret_cast<const v4u *>(xs)[lv1],
+              r2 = reinterpret_cast<const v4u *>(xs)[lv2], r3 = reinterpret_cast<const v4u *>(xs)[lv3];
+    asm volatile("" : : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+    const float3 x0 = make_float3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
+    const float3 x1 = make_float3(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
+    const float3 x2 = make_float3(__uint_as_float(r2.x), __uint_as_float(r2.y), __uint_as_float(r2.z));
+    const float3 x3 = make_float3(__uint_as_float(r3.x), __uint_as_float(r3.y), __uint_as_float(r3.z));
     const float Ds[9] = {x1.x - x0.x, x2.x - x0.x, x3.x - x0.x, x1.y - x0.y, x2.y - x0.y,
                          x3.y - x0.y, x1.z - x0.z, x2.z - x0.z, x3.z - x0.z};
 #pragma unroll
@@ -96,7 +105,8 @@ struct KernelArgs {
 };
 
 enum : int { DBG_UNUSED1 = 1, DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
-             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64 };
+             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64,
+             DBG_SKIP_VGATHER = 128, DBG_SKIP_OUT = 256 };
 
 // BLOCK is the largest workgroup the instantiation may be launched with; it only sets the VGPR
 // budget (1024 threads = 4 waves/SIMD = 128 VGPRs, 768 = 3 waves/SIMD = 168 VGPRs).
@@ -300,6 +310,19 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
+        // prefetch this thread's vertex incidence chunks (thread t gathers local vertex t) so their
+        // HBM latency hides behind the barriers and the d write
+        constexpr int kPre = 6;
+        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
+        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
+        int pc0 = 0, pc1 = 0;
+        uint2 pre[kPre];
+        if (tid < td.n_verts) {
+            pc0 = inc_off[tid];
+            pc1 = inc_off[tid + 1];
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : make_uint2(0u, 0u);
+        }
         __syncthreads();
         if (active) {
 #pragma unroll
@@ -314,14 +337,12 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 
         // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
         // Exclusive vertices go straight to grad, vertices shared with other tiles to the staging rows.
+        // (The first kPre chunks of this thread's first vertex were prefetched before the barriers.)
         const float gscale = a.grad_out ? *a.grad_out : 1.f;
-        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
-        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
         for (int v = tid; v < td.n_verts; v += nthr) {
-            const int c0 = inc_off[v], c1 = inc_off[v + 1];
+            const int c0 = v == tid ? pc0 : int(inc_off[v]), c1 = v == tid ? pc1 : int(inc_off[v + 1]);
             float gx = 0.f, gy = 0.f, gz = 0.f;
-            for (int c = c0; c < c1; ++c) {
-                const uint2 w = inc[c];
+            auto gather4 = [&](const uint2 w) {
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -334,10 +355,24 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                     gy += lc == 0 ? -sy : (lc == 1 ? da.y : (lc == 2 ? db.x : db.w));
                     gz += lc == 0 ? -sz : (lc == 1 ? da.z : (lc == 2 ? db.y : dc));
                 }
+            };
+            if (!(a.dbg & DBG_SKIP_VGATHER)) {
+                int c = c0;
+                if (v == tid) {
+#pragma unroll
+                    for (int q = 0; q < kPre; ++q)
+                        if (c0 + q < c1) gather4(pre[q]);
+                    c = c0 + kPre;
+                }
+                for (; c < c1; ++c) gather4(inc[c]);
             }
             float *dst = v < td.n_excl ? a.grad + size_t(a.gvid[td.vert_off + v]) * 3
                                        : a.stage + (size_t(td.stage_off) + size_t(v - td.n_excl)) * 3;
             const float sc = v < td.n_excl ? gscale : 1.f;
+            if (a.dbg & DBG_SKIP_OUT) {
+                if (gx == 1234.5f) dst[0] = gy + gz;
+                continue;
+            }
             dst[0] = gx * sc;
             dst[1] = gy * sc;
             dst[2] = gz * sc;
@@ -522,7 +557,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.dbg = e.dbg;
         const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
-        const bool small = e.block_threads <= 768;
+        const bool small = false;  // the 768-thread instantiation (168 VGPRs) schedules worse and spills more; unused
         if (e.grad && small)
             hipLaunchKernelGGL((tile_energy_kernel<true, 768>), grid, block, size_t(e.lds_bytes), stream, k);
         else if (e.grad)
