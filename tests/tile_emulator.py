@@ -113,18 +113,28 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
             pen, dpen = 0 * Jm, 0 * Jm
         Eb += float(pen[owned].sum())
         scal = np.where(owned, c2 * dpen, 0.0)
-        Fz = np.concatenate([F.reshape(sp, 9), np.zeros((1, 9))], axis=0)      # + zero slot
+        # LDS planes are addressed by lds_index(slot) = (slot & 3) * nq + (slot >> 2); neighbour and
+        # incidence entries hold those indices, the zero slot sits at index s_pad
+        nq = sp // 4
+        slots = np.arange(sp)
+        perm = (slots & 3) * nq + (slots >> 2)
+        Fz = np.zeros((sp + 1, 9))
+        Fz[perm] = F.reshape(sp, 9)
         deg = (nb != ZS).sum(axis=1).astype(np.float64)
-        H = deg[:, None] * Fz[:sp] - Fz[nb].sum(axis=1)
+        H = deg[:, None] * F.reshape(sp, 9) - Fz[nb].sum(axis=1)
         H[~owned] = 0.0
         Es += 0.5 * float((H * H).sum())
-        Hz = np.concatenate([H, np.zeros((1, 9))], axis=0)
-        Q = deg[:, None] * Hz[:sp] - Hz[nb].sum(axis=1)
+        Hz = np.zeros((sp + 1, 9))
+        Hz[perm] = H
+        Q = deg[:, None] * H - Hz[nb].sum(axis=1)
         P = c1 * Q.reshape(sp, 3, 3) + scal[:, None, None] * _cof(F)
         d = P @ np.transpose(dminv, (0, 2, 1))
         # per-vertex gather through the incidence lists, exactly as the kernel's last phase does
-        dz = np.concatenate([d, np.zeros((1, 3, 3))], axis=0)                   # + zero slot
-        contrib = np.concatenate([-dz.sum(axis=2)[:, None, :], np.transpose(dz, (0, 2, 1))], axis=1)  # [slot, a, xyz]
+        dz = np.zeros((sp + 1, 3, 3))                                           # LDS order + zero slot
+        dz[perm] = d
+        contrib = np.concatenate([-dz.sum(axis=2)[:, None, :], np.transpose(dz, (0, 2, 1))], axis=1)  # [lds idx, a, xyz]
+        lv_lds = np.zeros((sp + 1, 4), dtype=np.int64)
+        lv_lds[perm] = lv
         inc, inc_off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
         assert inc_off[0] == 0 and inc_off[-1] * 4 == len(inc) and np.all(np.diff(inc_off) >= 0)
         sl, la = inc >> 2, inc & 3
@@ -132,7 +142,7 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         assert np.all(la[~real] == 1)
         # every (slot, a) of a real slot appears exactly once, under the right vertex
         owner = np.repeat(np.arange(T["n_verts"]), 4 * np.diff(inc_off))
-        assert np.array_equal(lv[sl[real], la[real]], owner[real])
+        assert np.array_equal(lv_lds[sl[real], la[real]], owner[real])
         assert real.sum() == 4 * T["n_slots"]
         assert len(np.unique(inc[real])) == real.sum()
         gs = np.zeros((T["n_verts"], 3))

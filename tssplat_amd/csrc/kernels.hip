@@ -171,7 +171,6 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     float scal[4] = {0.f, 0.f, 0.f, 0.f};  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
     float e_b = 0.f, e_s = 0.f;
     if (active) {
-        float f8[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
@@ -192,13 +191,12 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 e_b += pen;
                 scal[p] = a.c2 * dpen;
             }
-            const int s = 4 * tid + p;
+            const int s = p * nq + tid;  // lds_index(4 * tid + p)
             FA[s] = make_float4(F[0], F[1], F[2], F[3]);
             FB[s] = make_float4(F[4], F[5], F[6], F[7]);
-            f8[p] = F[8];
+            FC[s] = F[8];
             __builtin_amdgcn_sched_barrier(0);
         }
-        reinterpret_cast<float4 *>(FC)[tid] = make_float4(f8[0], f8[1], f8[2], f8[3]);
     }
     __syncthreads();
     if (a.dbg & DBG_EXIT_AFTER_P1) {
@@ -209,18 +207,18 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
     float H[4][9];
     if (active && !(a.dbg & DBG_SKIP_P2)) {
-        const float4 own8 = reinterpret_cast<const float4 *>(FC)[tid];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
             const bool owned = (n01 & kOwnedBit) != 0;
             uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
-            const int s = 4 * tid + p;
+            const int s = p * nq + tid;
             if (a.dbg & DBG_LOCAL_GATHER2) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(s);
             const float4 fa = FA[s], fb = FB[s];
+            const float fc = FC[s];
             const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
             float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
-                            deg * fb.y, deg * fb.z, deg * fb.w, deg * comp(own8, p)};
+                            deg * fb.y, deg * fb.z, deg * fb.w, deg * fc};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 ga = FA[nb[k]], gb = FB[nb[k]];
@@ -254,11 +252,11 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
             for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int s = 4 * tid + p;
+                const int s = p * nq + tid;
                 FA[s] = make_float4(H[p][0], H[p][1], H[p][2], H[p][3]);
                 FB[s] = make_float4(H[p][4], H[p][5], H[p][6], H[p][7]);
+                FC[s] = H[p][8];
             }
-            reinterpret_cast<float4 *>(FC)[tid] = make_float4(H[0][8], H[1][8], H[2][8], H[3][8]);
         }
         __syncthreads();
 
@@ -272,9 +270,9 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
                 uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
                 const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
-                if (a.dbg & DBG_LOCAL_GATHER3) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(4 * tid + p);
+                if (a.dbg & DBG_LOCAL_GATHER3) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(p * nq + tid);
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
-                const int so = 4 * tid + p;
+                const int so = p * nq + tid;
                 const float4 ha = FA[so], hb = FB[so];
                 float P[9] = {deg * ha.x, deg * ha.y, deg * ha.z, deg * ha.w, deg * hb.x,
                               deg * hb.y, deg * hb.z, deg * hb.w, deg * FC[so]};
@@ -327,11 +325,11 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         if (active) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int s = 4 * tid + p;
+                const int s = p * nq + tid;
                 FA[s] = make_float4(D[p][0], D[p][1], D[p][2], D[p][3]);   // v1.xyz, v2.x
                 FB[s] = make_float4(D[p][4], D[p][5], D[p][6], D[p][7]);   // v2.yz, v3.xy
+                FC[s] = D[p][8];                                           // v3.z
             }
-            reinterpret_cast<float4 *>(FC)[tid] = make_float4(D[0][8], D[1][8], D[2][8], D[3][8]);  // v3.z
         }
         __syncthreads();
 

@@ -602,9 +602,9 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     if (q >= 0) {
                         int32_t qs = S.tet_stamp[q];
                         if (owned) {
-                            v = uint32_t(S.tet_slot[q]);  // by construction q is owned or halo here
+                            v = uint32_t(lds_index(S.tet_slot[q], nq));  // by construction q is owned or halo here
                         } else if (qs == st) {
-                            v = uint32_t(S.tet_slot[q]);  // halo tets only look at owned neighbours
+                            v = uint32_t(lds_index(S.tet_slot[q], nq));  // halo tets only look at owned neighbours
                         }
                     }
                     nb[k] = v;
@@ -663,7 +663,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     if (stet[sl] < 0) continue;
                     for (int a = 0; a < 4; ++a) {
                         int32_t v = S.vert_local[tets[4 * int64_t(stet[sl]) + a]];
-                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(sl) << 2) | uint32_t(a));
+                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq)) << 2) | uint32_t(a));
                     }
                 }
             }
