@@ -1,0 +1,182 @@
+"""CPU tests of the oracle itself: pinned against the reference's own `compute_G_matrix` golden
+vectors, analytic known answers, finite differences, and cross-checked between its three
+restatements (numpy float64, plain C float64, torch fp32 reference formulation)."""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import c_oracle, tet_energy_oracle as O
+from tssplat_amd import scenes
+
+
+@pytest.fixture(scope="module")
+def small():
+    sc = scenes.make_scene("kuhn4", 2)
+    return sc, O.prepare(sc.rest, sc.tets)
+
+
+def test_golden_G_from_reference(golden_dir):
+    """tests/golden/g_matrix_golden.npz was produced by the reference's compute_G_matrix
+    (geometry/mesh_utils.py:38-69); the oracle's G must reproduce it."""
+    z = np.load(os.path.join(golden_dir, "g_matrix_golden.npz"))
+    for key in ("aveg", "kuhn2"):
+        G = O.gradient_operator_dense(z[f"{key}_rest"], z[f"{key}_tets"])
+        ref = z[f"{key}_G"]
+        assert G.shape == ref.shape
+        assert np.abs(G - ref).max() <= 1e-11 * np.abs(ref).max()
+    # and the sparse global operator agrees with the per-tet blocks: F = G x
+    rest, tets = z["kuhn2_rest"], z["kuhn2_tets"]
+    Gs = O.gradient_operator_sparse(rest, tets)
+    assert Gs.shape == (9 * tets.shape[0], 3 * rest.shape[0]) and Gs.nnz == 36 * tets.shape[0]
+    x = np.random.default_rng(0).standard_normal(rest.shape)
+    _, Dminv = O.rest_operators(rest, tets)
+    F = O.deformation_gradient(x.astype(np.float32), tets, Dminv)
+    assert np.allclose(Gs @ x.astype(np.float32).astype(np.float64).reshape(-1), F.reshape(-1), atol=1e-10)
+
+
+def test_rest_state_and_affine_maps(small):
+    sc, cache = small
+    m = sc.n_tets
+    _, Dminv = O.rest_operators(sc.rest, sc.tets)
+    F = O.deformation_gradient(sc.rest, sc.tets, Dminv)
+    assert np.abs(F - np.eye(3)).max() < 1e-12                      # F(rest) = I
+    E, Es, Eb, g = O.energy_and_grad(sc.rest, cache, 1.0, 1.0, 2)
+    assert Es < 1e-9 and Eb == 0.0 and np.abs(g).max() < 1e-2      # fp32-rounded Dm^-1 leaves ~1e-7 noise in F
+    A = np.array([[1.1, 0.2, 0.0], [-0.1, 0.9, 0.3], [0.05, 0.0, 1.2]])
+    xa = sc.rest.astype(np.float64) @ A.T + np.array([0.3, -0.2, 0.1])
+    Fa = O.deformation_gradient(xa, sc.tets, Dminv)
+    assert np.abs(Fa - A).max() < 1e-12                             # F(Ax+b) = A for every tet
+    # L annihilates constants: smoothness vanishes on affine maps, penalty = m * max(-det A, 0)^p
+    R = np.diag([1.0, 1.0, -1.0])
+    xr = (sc.rest.astype(np.float64) @ R.T).astype(np.float32)
+    for order in (2, 4):
+        E, Es, Eb, _ = O.energy_and_grad(xr, cache, 1.0, 1.0, order)
+        assert Es < 1e-8 and abs(Eb - m) < 1e-4 * m
+    E, Es, Eb, g = O.energy_and_grad(xr, cache, 1.0, 1.0, 3)        # order not in {2,4}: penalty off (.cu:57-63)
+    assert Eb == 0.0
+
+
+def test_invariances_and_additivity(small):
+    sc, cache = small
+    x = scenes.deform(sc, 0.2).astype(np.float64)
+    E0, Es0, Eb0, g0 = O.energy_and_grad(x.astype(np.float32), cache, 1e-3, 2e-3, 2)
+    th = 0.7
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    xr = (x @ Rz.T + 0.5).astype(np.float32)
+    E1, Es1, Eb1, g1 = O.energy_and_grad(xr, cache, 1e-3, 2e-3, 2)
+    assert abs(E1 - E0) < 1e-4 * abs(E0)                            # rigid motions leave E unchanged (F -> R F)
+    assert np.linalg.norm(g1 - g0 @ Rz.T) < 1e-3 * np.linalg.norm(g0)
+    # block additivity over spheres: the sharding invariant
+    nv, nt = sc.n_vertices // 2, sc.n_tets // 2
+    ca = O.prepare(sc.rest[:nv], sc.tets[:nt])
+    cb = O.prepare(sc.rest[nv:], sc.tets[nt:] - nv)
+    Ea = O.energy_and_grad(x[:nv].astype(np.float32), ca, 1e-3, 2e-3, 2)
+    Eb_ = O.energy_and_grad(x[nv:].astype(np.float32), cb, 1e-3, 2e-3, 2)
+    assert abs(Ea[0] + Eb_[0] - E0) < 1e-12 * abs(E0)
+    assert np.abs(np.concatenate([Ea[3], Eb_[3]]) - g0).max() < 1e-12 * np.abs(g0).max()
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_finite_differences(small, order):
+    sc, cache = small
+    x = scenes.deform(sc, 0.3)
+    _, _, _, g = O.energy_and_grad(x, cache, 1e-3, 2e-3, order)
+    idx = np.random.default_rng(1).integers(0, g.size, 12)
+    fd = O.finite_difference_grad(x, cache, 1e-3, 2e-3, order, idx, h=1e-6)
+    assert np.abs(fd - g.reshape(-1)[idx]).max() <= 1e-6 * max(1.0, np.abs(fd).max())
+
+
+def test_matrix_form_equals_factored_form(small):
+    """x^T (G^T L^T L G) x / 2 == 1/2 |L G x|^2 and M x == G^T L^T L G x (float64)."""
+    sc, cache = small
+    M, G = O.biharmonic_matrix(sc.rest, sc.tets)
+    assert (abs(M - M.T) > 1e-9 * abs(M).max()).nnz == 0
+    x = scenes.deform(sc, 0.1)
+    xf = x.astype(np.float64).reshape(-1)
+    # unrounded operators on both sides
+    c_exact = O.prepare(sc.rest, sc.tets, round_fp32=False)
+    _, Es, _, g = O.energy_and_grad(x, c_exact, 1.0, 0.0, 2)
+    assert abs(0.5 * xf @ (M @ xf) - Es) <= 1e-9 * Es
+    assert np.abs((M @ xf).reshape(-1, 3) - g).max() <= 1e-8 * np.abs(g).max()
+
+
+def test_c_oracle_matches_numpy_oracle():
+    c_oracle.build()
+    for kind, S, sigma, order in [("kuhn4", 3, 0.3, 2), ("kuhn4", 3, 0.3, 4), ("cone", 2, 0.1, 2), ("kuhn3", 1, 0.0, 2)]:
+        sc = scenes.make_scene(kind, S)
+        cache = O.prepare(sc.rest, sc.tets)
+        assert np.array_equal(c_oracle.face_adjacency(sc.tets), cache.nbr)
+        x = scenes.deform(sc, sigma)
+        E, Es, Eb, g = O.energy_and_grad(x, cache, 3e-4, 2e-4, order, grad_output=0.7)
+        Ec, Esc, Ebc, gc = c_oracle.energy_and_grad(sc.rest, sc.tets, x, 3e-4, 2e-4, order, grad_output=0.7)
+        assert abs(E - Ec) <= 1e-12 * max(abs(E), 1e-30) + 1e-20
+        assert abs(Es - Esc) <= 1e-12 * max(Es, 1e-30) + 1e-20 and abs(Eb - Ebc) <= 1e-12 * max(Eb, 1e-30)
+        assert np.abs(g - gc).max() <= 1e-11 * np.abs(g).max() + 1e-15   # at rest g is pure cancellation noise
+
+
+def test_torch_reference_formulation_within_its_band(aveg):
+    """The "vanilla PyTorch" fp32 M-formulation (oracle/torch_energies.py) agrees with the float64
+    oracle inside SURVEY.md 8(c)'s band -- and needs that band: near rest it returns O(1) noise."""
+    torch = pytest.importorskip("torch")
+    from oracle import torch_energies as TE
+    rest, tets = aveg
+    rest, tets = rest[:], tets[:]
+    # a 3000-tet sub-mesh keeps the sparse products fast
+    keep = np.arange(3000)
+    used, inv = np.unique(tets[keep], return_inverse=True)
+    rest_s, tets_s = rest[used], inv.reshape(-1, 4).astype(np.int32)
+    ts = TE.TorchTetSpheres(rest_s, tets_s)
+    cache = O.prepare(rest_s, tets_s)
+    eps = 2.0 ** -23
+    rng = np.random.default_rng(5)
+    for sigma in (0.0, 1e-2, 5e-2):
+        x = (rest_s + sigma * rng.standard_normal(rest_s.shape)).astype(np.float32)
+        c1, c2 = 2e-4, 2e-4
+        E, Es, Eb, g = O.energy_and_grad(x, cache, c1, c2, 2)
+        A, nMx = O.tolerance_scales(x, cache)
+        e_t = float(TE.compute_energy(torch.from_numpy(x), ts, c1, c2, 2))
+        g_t = TE.compute_energy_backward(1.0, torch.from_numpy(x), ts, c1, c2, 2).numpy().astype(np.float64)
+        assert abs(e_t - E) <= 1e-5 * abs(E) + 8 * eps * c1 * A + 1e-5 * c2 * Eb
+        assert np.linalg.norm(g_t - g) <= 1e-5 * np.linalg.norm(g) + 8 * eps * c1 * nMx
+
+
+def test_non_manifold_is_rejected():
+    tets = np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]], dtype=np.int32)   # one face, three tets
+    with pytest.raises(ValueError):
+        O.face_adjacency(tets)
+    with pytest.raises(ValueError):
+        c_oracle.face_adjacency(tets)
+
+
+@settings(max_examples=25, deadline=None)
+@given(k=st.integers(1, 3), seed=st.integers(0, 10_000), sigma=st.floats(0.0, 0.5), order=st.sampled_from([2, 4]))
+def test_property_gradient_is_derivative(k, seed, sigma, order):
+    """Random small complexes: directional derivative of E matches g . dx."""
+    v, t = scenes.kuhn_ball(k)
+    rng = np.random.default_rng(seed)
+    rest = (v * rng.uniform(0.2, 2.0) + rng.uniform(-1, 1, 3)).astype(np.float32)
+    cache = O.prepare(rest, t)
+    x = (rest + sigma * 0.3 * rng.standard_normal(rest.shape)).astype(np.float32)
+    dx = rng.standard_normal(rest.shape)
+    dx /= np.linalg.norm(dx)
+    _, _, _, g = O.energy_and_grad(x, cache, 1e-2, 1e-2, order)
+    idx = np.arange(x.size)
+    # central difference along dx using the float64 energy
+    h = 1e-6
+    xp = x.astype(np.float64) + h * dx
+    xm = x.astype(np.float64) - h * dx
+
+    def E64(xx):
+        T = cache.tets
+        p = xx[T]
+        Ds = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]], axis=2)
+        F = Ds @ cache.Dminv
+        H = cache.L @ F.reshape(-1, 9)
+        pen, _ = O._penalty(O.det3(F), order)
+        return float(np.float32(1e-2)) * 0.5 * np.sum(H * H) + float(np.float32(1e-2)) * np.sum(pen)
+
+    dd = (E64(xp) - E64(xm)) / (2 * h)
+    assert abs(dd - float(np.sum(g * dx))) <= 1e-5 * max(1.0, abs(dd), np.linalg.norm(g))
+    assert idx.size == x.size

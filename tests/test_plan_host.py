@@ -1,0 +1,179 @@
+"""CPU tests of the host side of the product: the tiling plan built by libtssplat_amd.so
+(``host_only=True`` never touches HIP), replayed in float64 by tests/tile_emulator.py against
+the oracle, plus the C ABI's error behaviour.  No compute kernel runs here."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+from oracle import tet_energy_oracle as O
+from tssplat_amd import _capi, scenes
+import tile_emulator as TE
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from tssplat_amd import tet_spheres_ext
+    return tet_spheres_ext
+
+
+def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, **kw)
+    cache = O.prepare(sc.rest, sc.tets)
+    assert np.array_equal(TE.adjacency(ts), cache.nbr)
+    for sigma, order, go in cases:
+        x = scenes.deform(sc, sigma)
+        E, Es, Eb, g = O.energy_and_grad(x, cache, 5e-5, 2e-4, order, grad_output=go)
+        E2, Es2, Eb2, g2 = TE.emulate(ts, x, 5e-5, 2e-4, order, grad_output=go)
+        assert abs(E - E2) <= 1e-12 * abs(E)
+        assert abs(Es - Es2) <= 1e-12 * Es and abs(Eb - Eb2) <= 1e-12 * max(Eb, 1e-300)
+        assert np.abs(g - g2).max() <= 1e-11 * np.abs(g).max()
+    return ts
+
+
+@pytest.mark.parametrize("kind,S,kw", [
+    ("kuhn8", 3, {}),                                  # one tile per sphere, no halo
+    ("kuhn8", 2, dict(lds_budget_bytes=40000)),        # forced multi-tile
+    ("kuhn3", 40, {}),                                 # many tiny spheres packed into shared tiles
+    ("kuhn12", 1, {}),                                 # ~10k tets: bisected
+    ("kuhn12", 1, dict(balance_slots=False)),
+    ("kuhn12", 1, dict(max_threads=256, lds_budget_bytes=40960)),
+    ("kuhn12", 1, dict(debug_shuffle=True)),
+    ("cone", 2, {}),                                   # hub vertex of valence 1280
+    ("cone", 1, dict(lds_budget_bytes=30000)),
+])
+def test_plan_replays_to_oracle(ext, kind, S, kw):
+    sc = scenes.make_scene(kind, S)
+    ts = _check(ext, sc, kw, cases=((0.02, 2, 1.0), (0.3, 4, 0.5)))
+    info = ts.plan_info()
+    assert info["n_tets"] == sc.n_tets and info["n_vertices"] == sc.n_vertices
+    assert info["n_components"] == S
+    assert info["total_slots"] >= sc.n_tets
+    assert info["block_threads"] % 64 == 0 and 64 <= info["block_threads"] <= 1024
+    assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 163840)
+    assert 4 * info["block_threads"] >= info["max_slots"]
+
+
+def test_real_mesh_plan(ext, aveg):
+    rest, tets = aveg
+    sc = scenes.replicate_spheres(rest.astype(np.float64), tets, 2, seed=3)
+    ts = _check(ext, sc, {}, cases=((0.05, 2, 1.0),))
+    info = ts.plan_info()
+    assert info["n_tiles"] >= 2 * 7 and info["shared_vertex_copies"] > 0
+    # halo overhead of the partitioner on a TetWild-quality mesh stays moderate
+    assert info["total_slots"] / info["n_tets"] < 1.6
+
+
+def test_small_components_are_packed(ext):
+    sc = scenes.make_scene("kuhn3", 40)            # 162 tets each
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True)
+    info = ts.plan_info()
+    assert info["n_tiles"] < 10 and info["total_slots"] == sc.n_tets and info["shared_vertex_copies"] == 0
+
+
+def test_isolated_vertices_get_zero_gradient(ext):
+    v, t = scenes.kuhn_ball(2)
+    rest = np.concatenate([v, [[5.0, 5.0, 5.0], [6.0, 6.0, 6.0]]]).astype(np.float32)   # two unreferenced vertices
+    ts = ext.TetSpheres(rest.reshape(-1), t.reshape(-1), host_only=True)
+    x = rest + 0.05 * np.random.default_rng(0).standard_normal(rest.shape).astype(np.float32)
+    _, _, _, g = TE.emulate(ts, x, 1.0, 1.0, 2)
+    assert np.all(g[-2:] == 0.0)
+
+
+def test_veg_roundtrip_and_file_constructor(ext, tmp_path, aveg):
+    rest, tets = aveg
+    path = tmp_path / "mesh.veg"
+    scenes.write_veg(path, rest[:200], np.array([[0, 1, 2, 3]], dtype=np.int32))   # minimal valid file
+    v, t = scenes.read_veg(path)
+    assert np.array_equal(t, [[0, 1, 2, 3]]) and np.allclose(v, rest[:200])
+    scenes.write_veg(path, rest, tets)
+    ts = ext.TetSpheres(str(path), host_only=True)
+    assert ts.n == rest.shape[0] and ts.nele == tets.shape[0]
+    ref = ext.TetSpheres(rest.reshape(-1), tets.reshape(-1), host_only=True)
+    assert np.array_equal(TE.adjacency(ts), TE.adjacency(ref))
+    with pytest.raises(RuntimeError):
+        ext.TetSpheres(str(tmp_path / "missing.veg"), host_only=True)
+
+
+def test_error_behaviour(ext, capsys):
+    v, t = scenes.kuhn_ball(2)
+    v32 = v.astype(np.float32)
+    # index out of range
+    bad = t.copy()
+    bad[3, 2] = 10_000
+    with pytest.raises(RuntimeError, match="out of range"):
+        ext.TetSpheres(v32.reshape(-1), bad.reshape(-1), host_only=True)
+    # non-manifold: three tets on one face
+    nm_v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 1]], dtype=np.float32)
+    nm_t = np.array([[0, 1, 2, 3], [0, 2, 1, 4], [0, 1, 2, 5]], dtype=np.int32)
+    with pytest.raises(RuntimeError, match="non-manifold"):
+        ext.TetSpheres(nm_v.reshape(-1), nm_t.reshape(-1), host_only=True)
+    # singular rest tet
+    flat = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], dtype=np.float32)
+    with pytest.raises(RuntimeError, match="singular"):
+        ext.TetSpheres(flat.reshape(-1), np.array([0, 1, 2, 3], dtype=np.int32), host_only=True)
+    # 2-D arrays: the reference prints and returns an unusable object (tet_spheres.cpp:238-250)
+    empty = ext.TetSpheres(v32, t.reshape(-1), host_only=True)
+    assert "Wrong vertex type" in capsys.readouterr().err
+    with pytest.raises(RuntimeError, match="empty"):
+        empty.plan_info()
+    # a host_only handle refuses every device entry point, loudly
+    ts = ext.TetSpheres(v32.reshape(-1), t.reshape(-1), host_only=True)
+    lib = _capi.load()
+    rc = lib.tsamd_forward(ts._handle(), 1, 1.0, 1.0, 2, None, 1)
+    assert rc == 7 and b"host_only" in lib.tsamd_last_error()
+    # forcecast semantics: float64 / int64 inputs are converted like py::array::forcecast does
+    ts64 = ext.TetSpheres(v.reshape(-1), t.astype(np.int64).reshape(-1), host_only=True)
+    assert ts64.nele == t.shape[0]
+    # options struct versioning
+    o = _capi.make_options(host_only=1)
+    o.struct_size = 4
+    h = C.c_void_p()
+    assert lib.tsamd_create(v32.ctypes.data, v32.shape[0], t.ctypes.data, t.shape[0], C.byref(o), C.byref(h)) == 1
+
+
+def test_library_exports_every_declared_symbol():
+    """include/tssplat_amd.h is the contract: every function it declares must be exported."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "tssplat_amd.h")).read()
+    declared = set(re.findall(r"\b(tsamd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"tsamd_options", "tsamd_plan_info", "tsamd_tile_view", "tsamd_status", "tsamd_handle"}
+    lib = C.CDLL(_capi.lib_path())
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, f"declared in the header but not exported: {missing}"
+    assert declared == set(_capi.SIGNATURES), (declared ^ set(_capi.SIGNATURES))
+    assert b"gfx950" in _capi.load().tsamd_version()
+
+
+def test_import_path_shim_and_operator_surface(capsys):
+    """`from tet_spheres import tet_spheres_ext` (energies/smooth_barrier.py:6) must resolve here."""
+    from tet_spheres import tet_spheres_ext as shim
+    from tssplat_amd import tet_spheres_ext as real
+    assert shim is real
+    for name in ("TetSpheres", "forward", "backward", "random_x", "grad_limit"):
+        assert hasattr(shim, name)
+    from tssplat_amd.energies import SmoothnessBarrierEnergy, SmoothnessBarrierFunc
+    import inspect
+    assert list(inspect.signature(SmoothnessBarrierFunc.forward).parameters) == ["x_cur", "tet_sp", "c1", "c2", "order"]
+    assert list(inspect.signature(SmoothnessBarrierEnergy.forward).parameters) == ["self", "x", "it", "c1", "c2"]
+    rx = real.random_x(type("T", (), {"n": 7})())
+    assert tuple(rx.shape) == (7, 3)
+
+
+def test_coeff_schedule_matches_reference_formula():
+    """energies/smooth_barrier.py:47-58: x1 at it=0, x16 from it=1200; order switches after 1000."""
+    import math
+    from tssplat_amd.energies import SmoothnessBarrierEnergy
+
+    class F:
+        smooth_eng_coeff, barrier_coeff, increase_order_iter = 2e-4, 3e-4, 1000
+
+    fake = type("M", (), {"FLAGS": F})()
+    for it in (0, 1, 300, 600, 1199, 1200, 5000):
+        c1, c2 = SmoothnessBarrierEnergy.coeff_scheduler(fake, it)
+        mult = math.pow(2, abs(math.sin(min(it / 300.0 / 4 * 0.5 * math.pi, 0.5 * math.pi))) * 4)
+        assert c1 == F.smooth_eng_coeff * mult and c2 == F.barrier_coeff * mult
+    assert SmoothnessBarrierEnergy.coeff_scheduler(fake, 0) == (2e-4, 3e-4)
+    assert abs(SmoothnessBarrierEnergy.coeff_scheduler(fake, 1200)[0] / 2e-4 - 16) < 1e-12

@@ -1,0 +1,147 @@
+"""world_size-2 `gloo` test of the N>1 path on CPU: sphere partitioning, rank-local slices, the
+scalar energy all-reduce and the rank-local gradient.
+
+The rank-local evaluator on a GPU box is the HIP-backed SmoothnessBarrierEnergy; here it is an
+oracle-backed stand-in with the same interface (this is a TEST -- the product never imports the
+oracle), so what is exercised is exactly the host logic of tssplat_amd/sharding.py.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tssplat_amd import scenes
+from tssplat_amd.sharding import ShardedSmoothnessBarrierEnergy, partition_spheres
+
+
+class _Flags:
+    smooth_eng_coeff = 2e-4 / 5
+    barrier_coeff = 2e-4
+    increase_order_iter = 1000
+
+
+class _OracleFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cache, c1, c2, order):
+        from oracle import tet_energy_oracle as O
+        E, _, _, g = O.energy_and_grad(x.detach().numpy(), cache, c1, c2, order)
+        ctx.g = torch.from_numpy(g.astype(np.float32))
+        return torch.tensor(E, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, go):
+        return ctx.g * go, None, None, None, None
+
+
+class _OracleEnergy(torch.nn.Module):
+    """Stand-in for SmoothnessBarrierEnergy (same constructor / forward signature)."""
+
+    def __init__(self, tet_v, tet_f, FLAGS):
+        super().__init__()
+        from oracle import tet_energy_oracle as O
+        self.cache = O.prepare(np.asarray(tet_v, np.float32), np.asarray(tet_f, np.int32))
+        self.FLAGS = FLAGS
+
+    def coeff_scheduler(self, it):
+        return self.FLAGS.smooth_eng_coeff, self.FLAGS.barrier_coeff
+
+    def forward(self, x, it, c1, c2):
+        return _OracleFunc.apply(x, self.cache, c1, c2, 4 if it > self.FLAGS.increase_order_iter else 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene():
+    # five spheres of different sizes so that the balanced cut is not the trivial one
+    parts = [scenes.kuhn_ball(k) for k in (3, 2, 4, 2, 3)]
+    rest, tets, vo, to = [], [], [0], [0]
+    rng = np.random.default_rng(0)
+    for v, t in parts:
+        rest.append((v * rng.uniform(0.1, 0.3) + rng.uniform(-0.5, 0.5, 3)).astype(np.float32))
+        tets.append(t + vo[-1])
+        vo.append(vo[-1] + v.shape[0])
+        to.append(to[-1] + t.shape[0])
+    rest = np.concatenate(rest)
+    tets = np.concatenate(tets).astype(np.int32)
+    x = (rest + 0.05 * rng.standard_normal(rest.shape)).astype(np.float32)
+    return rest, tets, np.array(vo), np.array(to), x
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rest, tets, vo, to, x = _scene()
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
+        lo, hi = mod.vertex_range
+        xl = torch.from_numpy(x[lo:hi]).requires_grad_(True)
+        c1, c2 = mod.coeff_scheduler(0)
+        e = mod(xl, 0, c1, c2)
+        (2.0 * e).backward()
+        out[rank] = (float(e), mod.sphere_range, (lo, hi), xl.grad.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partition_properties():
+    counts = [3072] * 64
+    for w in (1, 2, 4, 8):
+        r = partition_spheres(counts, w)
+        assert r[0][0] == 0 and r[-1][1] == 64 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        sizes = [hi - lo for lo, hi in r]
+        assert max(sizes) - min(sizes) <= 1
+    r = partition_spheres([100, 1, 1, 1, 1, 1], 3)
+    assert r[0] == (0, 1) and r[-1][1] == 6 and all(hi > lo for lo, hi in r)
+    r = partition_spheres([5, 5], 4)                       # more ranks than spheres
+    assert sum(hi - lo for lo, hi in r) == 2 and all(hi - lo <= 1 for lo, hi in r)
+
+
+def test_two_ranks_match_unsharded_oracle():
+    from oracle import tet_energy_oracle as O
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    rest, tets, vo, to, x = _scene()
+    cache = O.prepare(rest, tets)
+    E, _, _, g = O.energy_and_grad(x, cache, _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2, grad_output=2.0)
+    covered = np.zeros(rest.shape[0], dtype=bool)
+    for rank in range(world):
+        e, srange, (lo, hi), grad = out[rank]
+        assert abs(e - E) <= 2e-6 * abs(E)                 # every rank sees the job-wide energy
+        assert np.abs(grad - g[lo:hi]).max() <= 1e-5 * np.abs(g).max()   # and only its own gradient slice
+        assert not covered[lo:hi].any()
+        covered[lo:hi] = True
+    assert covered.all()
+    assert out[0][1][1] == out[1][1][0]                    # contiguous sphere ranges
+
+
+def test_single_process_is_identity():
+    rest, tets, vo, to, x = _scene()
+    mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
+    assert mod.world_size == 1 and mod.vertex_range == (0, rest.shape[0])
+    xl = torch.from_numpy(x).requires_grad_(True)
+    e = mod(xl, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff)
+    e.backward()
+    from oracle import tet_energy_oracle as O
+    E, _, _, g = O.energy_and_grad(x, O.prepare(rest, tets), _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2)
+    assert abs(float(e) - E) <= 2e-6 * abs(E)
+    assert np.abs(xl.grad.numpy() - g).max() <= 1e-5 * np.abs(g).max()
+
+
+def test_rejects_spheres_that_share_vertices():
+    rest, tets, vo, to, _ = _scene()
+    bad = tets.copy()
+    bad[0, 0] = vo[-1] - 1        # first sphere now references a vertex of the last one
+    with pytest.raises(ValueError):
+        ShardedSmoothnessBarrierEnergy(rest, bad, _Flags, vo, to, rank=0, world_size=2, local_factory=_OracleEnergy)

@@ -47,7 +47,7 @@ def finish_lists(ts):
         return np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32)
     off_a = np.ctypeslib.as_array(off, shape=(k + 1,)).copy()
     ne = int(off_a[-1])
-    idx_a = np.ctypeslib.as_array(idx, shape=(max(ne, 1),)).copy()[:ne]
+    idx_a = np.ctypeslib.as_array(idx, shape=(ne,)).copy() if ne else np.zeros(0, np.int32)
     return np.ctypeslib.as_array(vid, shape=(k,)).copy(), off_a, idx_a
 
 

@@ -44,6 +44,26 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def build_variant(name: str, extra_device_flags: list[str]) -> str:
+    """Experiment helper: build libtssplat_amd_<name>.so with extra device flags (e.g. -DTSAMD_...).
+    Select it at run time with TSSPLAT_AMD_LIB=<path>."""
+    hipcc = _hipcc()
+    out = os.path.join(_HERE, f"libtssplat_amd_{name}.so")
+    os.makedirs(_OBJ, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(_OBJ, f"{os.path.splitext(src)[0]}_{name}.o")
+        if src.endswith(".hip"):
+            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS + extra_device_flags
+        else:
+            cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
+                                           os.path.join(CSRC, src), "-o", obj]
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([hipcc, "-shared", "-o", out] + objs + [f"--offload-arch={ARCH}", "-pthread"])
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile (if stale) and return the path of libtssplat_amd.so."""
     stamp = os.path.join(_OBJ, "digest")
@@ -55,12 +75,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(_OBJ, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS
         if src.endswith(".hip"):
-            cmd += DEVICE_FLAGS
-        else:
-            cmd += ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
-            # host-only translation units: put -x before the file
+            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS
+        else:   # host-only translation units
             cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
                                            os.path.join(CSRC, src), "-o", obj]
         if verbose:

@@ -102,6 +102,9 @@ def load(build_if_missing: bool = True):
     # two runtimes without devices ("no HIP device is visible").
     import torch  # noqa: F401
     path = _build.LIB
+    override = os.environ.get("TSSPLAT_AMD_LIB")       # experiment builds (tssplat_amd._build.build_variant)
+    if override:
+        path, build_if_missing = override, False
     if build_if_missing:
         try:
             path = _build.build()

@@ -27,6 +27,14 @@ namespace tsamd {
 namespace {
 
 constexpr int kWave = 64;
+
+// Scheduling fence between the four slots a lane processes in a pass (build with
+// -DTSAMD_NO_SLOT_FENCE to let the compiler interleave them).
+#ifdef TSAMD_NO_SLOT_FENCE
+#define SLOT_FENCE() ((void)0)
+#else
+#define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float det3(const float *F)
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
             FA[s] = make_float4(F[0], F[1], F[2], F[3]);
             FB[s] = make_float4(F[4], F[5], F[6], F[7]);
             FC[s] = F[8];
-            __builtin_amdgcn_sched_barrier(0);
+            SLOT_FENCE();
         }
     }
     __syncthreads();
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 H[p][c] = acc[c];
             }
             e_s += 0.5f * sq;
-            __builtin_amdgcn_sched_barrier(0);  // keep one slot's gathers in flight, not four (VGPR budget)
+            SLOT_FENCE();  // keep one slot's gathers in flight, not four (VGPR budget)
         }
     }
     __syncthreads();  // every read of F is done; overwrite it with H in place
@@ -300,7 +308,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                     for (int i = 0; i < 3; ++i)
                         D[p][3 * k + i] = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
                                           P[3 * i + 2] * comp(dm[3 * k + 2], p);
-                __builtin_amdgcn_sched_barrier(0);
+                SLOT_FENCE();
             }
         } else {
 #pragma unroll

@@ -1,0 +1,123 @@
+"""Sharding tet-spheres over the GPUs of a node (one process per GPU, torch.distributed / RCCL).
+
+Tet-spheres share no vertices and no faces: the reference concatenates them with a running
+vertex offset (/root/reference/geometry/tetmesh_geometry.py:310-331), so the operators are
+block-diagonal and ``E = sum_s E_s``.  Each rank therefore owns a contiguous range of whole
+spheres -- its slice of ``x`` and of the gradient -- and the path needs exactly one exchange
+per evaluation: the sum of the scalar energies (8 bytes over xGMI, latency bound, issued
+asynchronously so it never sits on the gradient's critical path).  No gradient exchange.
+
+The reference itself has no distributed code; this is new host logic, covered
+by world_size-2 gloo tests on CPU (tests/test_sharding_gloo.py).
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy"]
+
+
+def partition_spheres(tets_per_sphere: Sequence[int], world_size: int) -> list[tuple[int, int]]:
+    """Contiguous sphere ranges ``[lo, hi)`` per rank, balanced on tet count.
+
+    Greedy prefix cut at multiples of ``total / world_size``; every rank gets at least one sphere
+    while spheres last, ranks beyond the sphere count get an empty range.
+    """
+    counts = np.asarray(tets_per_sphere, dtype=np.int64)
+    S = int(counts.size)
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    prefix = np.concatenate([[0], np.cumsum(counts)])
+    total = int(prefix[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        c = int(np.argmin(np.abs(prefix - target)))          # nearest sphere boundary
+        lo = cuts[-1] + 1 if S >= world_size else cuts[-1]   # non-empty ranges while spheres last
+        hi = S - (world_size - r) if S >= world_size else S
+        cuts.append(int(min(max(c, lo), max(hi, lo) if S >= world_size else S)))
+    cuts.append(S)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+class _AddGlobal(torch.autograd.Function):
+    """``local + (global - local)`` with the gradient of ``local`` only: the forward value is the
+    job-wide energy, the backward pass stays rank-local (each rank owns its vertices)."""
+
+    @staticmethod
+    def forward(ctx, local, global_value):
+        return global_value.to(local.device, local.dtype).reshape(local.shape).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return grad_out, None
+
+
+def all_reduce_energy(local_energy: torch.Tensor, group=None, async_op: bool = False):
+    """Sum the scalar energies over ranks.  Returns the reduced tensor (and the work handle when
+    ``async_op``).  With one rank or no initialised process group it is the identity."""
+    e = local_energy.detach().clone().reshape(1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return (e.reshape(()), None) if async_op else e.reshape(())
+    work = dist.all_reduce(e, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return (e.reshape(()), work) if async_op else e.reshape(())
+
+
+class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
+    """``SmoothnessBarrierEnergy`` over this rank's spheres + the scalar all-reduce.
+
+    Parameters mirror the reference module (/root/reference/energies/smooth_barrier.py:34-45) plus
+    the sphere layout: ``sphere_vertex_offsets`` / ``sphere_tet_offsets`` (``S+1`` entries each,
+    as produced by the multi-sphere geometry's ``base_vid`` bookkeeping).  ``forward`` takes the
+    rank-local slice ``x[v_lo:v_hi]`` (use :attr:`vertex_range`) and returns the JOB-WIDE energy;
+    its gradient w.r.t. the local slice is the local gradient.
+
+    ``local_factory(rest_local, tets_local, FLAGS)`` builds the rank-local evaluator; it defaults
+    to the HIP-backed ``SmoothnessBarrierEnergy`` and exists so the CPU tests can exercise the
+    partition / collective logic with an oracle-backed stand-in.
+    """
+
+    def __init__(self, tet_v, tet_f, FLAGS, sphere_vertex_offsets, sphere_tet_offsets, group=None,
+                 rank: int | None = None, world_size: int | None = None,
+                 local_factory: Callable | None = None):
+        super().__init__()
+        initialised = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.rank = rank if rank is not None else (dist.get_rank(group) if initialised else 0)
+        self.world_size = world_size if world_size is not None else (dist.get_world_size(group) if initialised else 1)
+        vo = np.asarray(sphere_vertex_offsets, dtype=np.int64)
+        to = np.asarray(sphere_tet_offsets, dtype=np.int64)
+        if vo.size != to.size or vo.size < 1:
+            raise ValueError("sphere offset arrays must both have S+1 entries")
+        self.ranges = partition_spheres(np.diff(to), self.world_size)
+        lo, hi = self.ranges[self.rank]
+        self.sphere_range = (lo, hi)
+        self.vertex_range = (int(vo[lo]), int(vo[hi]))
+        self.tet_range = (int(to[lo]), int(to[hi]))
+        v = np.asarray(tet_v).reshape(-1, 3)[self.vertex_range[0]:self.vertex_range[1]]
+        f = np.asarray(tet_f).reshape(-1, 4)[self.tet_range[0]:self.tet_range[1]] - self.vertex_range[0]
+        if f.size and (f.min() < 0 or f.max() >= max(v.shape[0], 1)):
+            raise ValueError("a tet references a vertex outside its sphere range: spheres must not share vertices")
+        if local_factory is None:
+            from .energies import SmoothnessBarrierEnergy
+            local_factory = SmoothnessBarrierEnergy
+        self.local = local_factory(v, f, FLAGS) if v.shape[0] else None
+        self.FLAGS = FLAGS
+
+    def coeff_scheduler(self, it):
+        if self.local is not None:
+            return self.local.coeff_scheduler(it)
+        from .energies import SmoothnessBarrierEnergy
+        return SmoothnessBarrierEnergy.coeff_scheduler(self, it)
+
+    def forward(self, x_local: torch.Tensor, it, c1, c2):
+        if self.local is not None:
+            e_local = self.local(x_local, it, c1, c2)
+        else:                                   # more ranks than spheres: contribute zero
+            e_local = x_local.sum() * 0.0
+        e_global = all_reduce_energy(e_local, self.group)
+        return _AddGlobal.apply(e_local, e_global)
