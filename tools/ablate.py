@@ -40,6 +40,12 @@ def main():
     ap.add_argument("--masks", default="")
     ap.add_argument("--shuffle", action="store_true")
     args = ap.parse_args()
+    # the production library has the switches compiled out; build / select the ablation variant
+    from tssplat_amd import _build
+    variant = os.path.join(os.path.dirname(_build.LIB), "libtssplat_amd_ablation.so")
+    if not os.path.exists(variant):
+        variant = _build.build_variant("ablation", ["-DTSAMD_ABLATION"])
+    os.environ.setdefault("TSSPLAT_AMD_LIB", variant)
     import torch
     from tssplat_amd import _capi, scenes, tet_spheres_ext as T
     lib = _capi.load()

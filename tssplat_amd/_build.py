@@ -57,7 +57,8 @@ def build_variant(name: str, extra_device_flags: list[str]) -> str:
             cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS + extra_device_flags
         else:
             cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
-                                           os.path.join(CSRC, src), "-o", obj]
+                                           os.path.join(CSRC, src), "-o", obj] + \
+                  [f for f in extra_device_flags if f.startswith("-D")]
         subprocess.check_call(cmd)
         objs.append(obj)
     subprocess.check_call([hipcc, "-shared", "-o", out] + objs + [f"--offload-arch={ARCH}", "-pthread"])

@@ -365,6 +365,9 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
 int tsamd_debug_set_ablation(tsamd_handle *h, int flags)
 {
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "handle is null");
+#ifndef TSAMD_ABLATION
+    if (flags) return fail(TSAMD_ERR_INVALID_ARGUMENT, "this build has no ablation switches (compile with -DTSAMD_ABLATION)");
+#endif
     h->dbg = flags;
     return TSAMD_OK;
 }

@@ -109,15 +109,28 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
-    int dbg;  // ablation switches for tools/ablate.py (0 in production)
+    int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
 };
 
-enum : int { DBG_UNUSED1 = 1, DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
-             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64,
-             DBG_SKIP_VGATHER = 128, DBG_SKIP_OUT = 256 };
+enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
+             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64, DBG_SKIP_VGATHER = 128, DBG_SKIP_OUT = 256 };
 
-// BLOCK is the largest workgroup the instantiation may be launched with; it only sets the VGPR
-// budget (1024 threads = 4 waves/SIMD = 128 VGPRs, 768 = 3 waves/SIMD = 168 VGPRs).
+#ifdef TSAMD_ABLATION
+#define DBG(flag) ((a.dbg & (flag)) != 0)
+#else
+#define DBG(flag) false
+#endif
+
+// One workgroup = one tile.  LDS map (SA = s_pad + 4 slots incl. the all-zero slot at index s_pad,
+// VP = vertices rounded up to 4):
+//   [0, 16 SA)        FA: float4 per slot  (F[0..3], later H, addressed by lds_index(slot))
+//   [16 SA, 32 SA)    FB: float4 per slot  (F[4..7])
+//   [32 SA, 36 SA)    FC: float  per slot  (F[8])
+//   [36 SA, +16 VP)   xs: float4 per local vertex (staged positions)
+//   [0, 48 SA)        DV: 4 planes (one per local tet vertex) of 3 floats per slot -- the per-tet
+//                     vertex forces, written over F/H/xs once those are dead
+//   then 256 B of reduction scratch.
+// BLOCK only sets the VGPR budget (1024 threads = 4 waves/SIMD = 128 VGPRs).
 template <bool WITH_GRAD, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 {
@@ -141,7 +154,9 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     float4 *FB = FA + SA;
     float *FC = reinterpret_cast<float *>(FB + SA);
     float4 *xs = reinterpret_cast<float4 *>(FC + SA);
-    double *red = reinterpret_cast<double *>(xs + VP);
+    float *DV = reinterpret_cast<float *>(smem);
+    const int lds_main = 36 * SA + 16 * VP > 48 * SA ? 36 * SA + 16 * VP : 48 * SA;
+    double *red = reinterpret_cast<double *>(smem + lds_main);
 
     const bool active = tid < nq;
     const uint4 *pl = reinterpret_cast<const uint4 *>(a.blob + td.blob_off);
@@ -169,7 +184,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         FC[ZS] = 0.f;
     }
     __syncthreads();
-    if (a.dbg & DBG_EXIT_AFTER_LOAD) {
+    if (DBG(DBG_EXIT_AFTER_LOAD)) {
         float chk = dm[0].x + dm[4].y + dm[8].z + float(q_lv01.x ^ q_lv23.y ^ q_nb01.z ^ q_nb23.w) + xs[tid % td.n_verts].x;
         if (chk == 12345.678f) a.partials[0] = chk;
         return;
@@ -207,42 +222,47 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         }
     }
     __syncthreads();
-    if (a.dbg & DBG_EXIT_AFTER_P1) {
+    if (DBG(DBG_EXIT_AFTER_P1)) {
         if (e_b == 12345.678f) a.partials[0] = e_b;
         return;
     }
 
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
+    // With the balanced slot order, position p of lane t is item p * nq + t and items below n_owned
+    // are the owned ones, so `owned` is uniform across all but one wave per position: halo slots
+    // skip their twelve gathers with a real branch.
     float H[4][9];
-    if (active && !(a.dbg & DBG_SKIP_P2)) {
+    if (active && !DBG(DBG_SKIP_P2)) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
-            const bool owned = (n01 & kOwnedBit) != 0;
-            uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
-            const int s = p * nq + tid;
-            if (a.dbg & DBG_LOCAL_GATHER2) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(s);
-            const float4 fa = FA[s], fb = FB[s];
-            const float fc = FC[s];
-            const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
-            float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
-                            deg * fb.y, deg * fb.z, deg * fb.w, deg * fc};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 ga = FA[nb[k]], gb = FB[nb[k]];
-                const float gc = FC[nb[k]];
-                acc[0] -= ga.x; acc[1] -= ga.y; acc[2] -= ga.z; acc[3] -= ga.w;
-                acc[4] -= gb.x; acc[5] -= gb.y; acc[6] -= gb.z; acc[7] -= gb.w;
-                acc[8] -= gc;
-            }
-            float sq = 0.f;
+            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
+            if (n01 & kOwnedBit) {
+                uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
+                const int s = p * nq + tid;
+                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(s);
+                const float4 fa = FA[s], fb = FB[s];
+                const float fc = FC[s];
+                const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
+                float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
+                                deg * fb.y, deg * fb.z, deg * fb.w, deg * fc};
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                acc[c] = owned ? acc[c] : 0.f;
-                sq += acc[c] * acc[c];
-                H[p][c] = acc[c];
+                for (int k = 0; k < 4; ++k) {
+                    const float4 ga = FA[nb[k]], gb = FB[nb[k]];
+                    const float gc = FC[nb[k]];
+                    acc[0] -= ga.x; acc[1] -= ga.y; acc[2] -= ga.z; acc[3] -= ga.w;
+                    acc[4] -= gb.x; acc[5] -= gb.y; acc[6] -= gb.z; acc[7] -= gb.w;
+                    acc[8] -= gc;
+                }
+                float sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    sq += acc[c] * acc[c];
+                    H[p][c] = acc[c];
+                }
+                e_s += 0.5f * sq;
             }
-            e_s += 0.5f * sq;
             SLOT_FENCE();  // keep one slot's gathers in flight, not four (VGPR budget)
         }
     }
@@ -250,9 +270,9 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 
     if (WITH_GRAD) {
         if (active) {
-            // Dm^-1 and the vertex ids are needed again by the scatter.  Re-issuing their 11 loads here (L2-resident: the
-            // tile was streamed microseconds ago) instead of pinning 36 VGPRs across pass 2 keeps
-            // the kernel inside 128 VGPRs = 16 waves/CU.
+            // Dm^-1 and the vertex ids are needed again by pass 3.  Re-issuing their 11 loads here
+            // instead of pinning 44 VGPRs across pass 2 keeps the kernel inside 128 VGPRs
+            // (16 waves/CU) without scratch spills.
             q_lv01 = pl[0 * nq + tid];
             q_lv23 = pl[1 * nq + tid];
             const float4 *dpl = reinterpret_cast<const float4 *>(pl + 4 * nq);
@@ -269,16 +289,16 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         __syncthreads();
 
         // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T (per-tet vertex forces) ----
-        // d[i][k] = sum_j P[i][j] Dminv[k][j] is the force on local vertex k+1; vertex 0 gets -(sum).
-        // Held in registers across the barrier, then written over H (all reads of H are done by then).
+        // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
+        // Held in registers across the barrier, then written over F/H/xs (all dead by then).
         float D[4][9];
-        if (active && !(a.dbg & DBG_SKIP_P3)) {
+        if (active && !DBG(DBG_SKIP_P3)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
                 uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
                 const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
-                if (a.dbg & DBG_LOCAL_GATHER3) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(p * nq + tid);
+                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(p * nq + tid);
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
                 const int so = p * nq + tid;
                 const float4 ha = FA[so], hb = FB[so];
@@ -330,18 +350,26 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
             for (int q = 0; q < kPre; ++q) pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : make_uint2(0u, 0u);
         }
         __syncthreads();
+        // ---- write the vertex forces: plane a holds (fx, fy, fz) of local vertex a for every slot ----
+        const int plane = 3 * SA;  // floats per plane
         if (active) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int s = p * nq + tid;
-                FA[s] = make_float4(D[p][0], D[p][1], D[p][2], D[p][3]);   // v1.xyz, v2.x
-                FB[s] = make_float4(D[p][4], D[p][5], D[p][6], D[p][7]);   // v2.yz, v3.xy
-                FC[s] = D[p][8];                                           // v3.z
+                float *d0 = DV + 3 * (p * nq + tid);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    d0[i] = -(D[p][i] + D[p][3 + i] + D[p][6 + i]);
+                    d0[plane + i] = D[p][i];
+                    d0[2 * plane + i] = D[p][3 + i];
+                    d0[3 * plane + i] = D[p][6 + i];
+                }
             }
         }
+        if (tid < 12) DV[(tid / 3) * plane + 3 * ZS + tid % 3] = 0.f;  // the zero slot of every plane
         __syncthreads();
 
         // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
+        // Entry = (lds slot << 2) | local vertex; its force sits at DV[a * plane + 3 * slot].
         // Exclusive vertices go straight to grad, vertices shared with other tiles to the staging rows.
         // (The first kPre chunks of this thread's first vertex were prefetched before the barriers.)
         const float gscale = a.grad_out ? *a.grad_out : 1.f;
@@ -352,17 +380,13 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint32_t sl = ent[q] >> 2, lc = ent[q] & 3u;
-                    const float4 da = FA[sl], db = FB[sl];
-                    const float dc = FC[sl];
-                    // a=1: (da.x da.y da.z)  a=2: (da.w db.x db.y)  a=3: (db.z db.w dc)  a=0: -(sum)
-                    const float sx = da.x + da.w + db.z, sy = da.y + db.x + db.w, sz = da.z + db.y + dc;
-                    gx += lc == 0 ? -sx : (lc == 1 ? da.x : (lc == 2 ? da.w : db.z));
-                    gy += lc == 0 ? -sy : (lc == 1 ? da.y : (lc == 2 ? db.x : db.w));
-                    gz += lc == 0 ? -sz : (lc == 1 ? da.z : (lc == 2 ? db.y : dc));
+                    const float *f = DV + (ent[q] & 3u) * plane + 3 * (ent[q] >> 2);
+                    gx += f[0];
+                    gy += f[1];
+                    gz += f[2];
                 }
             };
-            if (!(a.dbg & DBG_SKIP_VGATHER)) {
+            if (!DBG(DBG_SKIP_VGATHER)) {
                 int c = c0;
                 if (v == tid) {
 #pragma unroll
@@ -375,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
             float *dst = v < td.n_excl ? a.grad + size_t(a.gvid[td.vert_off + v]) * 3
                                        : a.stage + (size_t(td.stage_off) + size_t(v - td.n_excl)) * 3;
             const float sc = v < td.n_excl ? gscale : 1.f;
-            if (a.dbg & DBG_SKIP_OUT) {
+            if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
                 continue;
             }

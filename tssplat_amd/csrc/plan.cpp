@@ -413,8 +413,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             c = ce;
         }
     }
-    // 36 B of LDS per slot + 16 B per vertex at ~0.27 vertices per slot
-    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 144) / 41);
+    // LDS per slot: max(36 B + 16 B per vertex at ~0.27 vertices per slot, 48 B of vertex forces)
+    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / 48);
     int64_t target = opt.target_owned > 0 ? opt.target_owned : int64_t(0.70 * double(s_cap));
     target = std::max<int64_t>(1, target);
 

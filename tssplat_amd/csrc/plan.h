@@ -57,7 +57,9 @@ inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts)
 {
     const int64_t sa = s_pad + 4;                 // + the all-zero slot, kept 16 B aligned
     const int64_t vp = (n_verts + 3) & ~int64_t(3);
-    return 36 * sa + 16 * vp + 256;               // F / H / d planes, x (float4), reduction scratch
+    const int64_t fx = 36 * sa + 16 * vp;         // F / H planes + staged positions (float4)
+    const int64_t dv = 48 * sa;                   // 4 planes of per-vertex forces, aliasing the above
+    return (fx > dv ? fx : dv) + 256;             // + reduction scratch
 }
 
 struct Plan {
