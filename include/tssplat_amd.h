@@ -147,6 +147,10 @@ int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_ker
 /* Diagnostic only (tools/ablate.py): switch parts of the tile kernel off to price them.
  * Any nonzero value makes results WRONG; production code never calls this. */
 int tsamd_debug_set_ablation(tsamd_handle *h, int flags);
+/* Diagnostic only, meaningful in -DTSAMD_ABLATION builds: the first call arms 16 shader-clock
+ * stamps per tile (phase boundaries seen by thread 0 of each workgroup), later calls copy the
+ * stamps of the most recent evaluation to host_out (capacity >= 16 * n_tiles). */
+int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capacity);
 
 /* out[i] = in[i] * (*scalar_dev); in == out allowed. */
 int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream);

@@ -93,10 +93,13 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
     for T in plan_tiles(ts):
         sp, pl = T["s_pad"], T["planes"]
         ZS = sp
-        lv = np.stack([pl[0] & 0x7fff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
+        lv16 = np.stack([pl[0] & 0x7fff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
+        assert np.all(lv16 % 16 == 0), "vertex fields are byte offsets into float4 positions"
+        lv = lv16 // 16
         owned = (pl[0] & OWNED) != 0
         assert np.array_equal(owned, (pl[2] & OWNED) != 0), "owned bit must agree in lv and nbr planes"
-        nb = np.stack([pl[2] & 0x7fff, pl[2] >> 16, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
+        nb = np.stack([pl[2] & 0x1fff, (pl[2] >> 16) & 0x1fff, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
+        deg_packed = (pl[2] >> 29).astype(np.int64)
         dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
         assert owned.sum() == T["n_owned"]
         xs = x[T["gvid"]]
@@ -120,7 +123,8 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         perm = (slots & 3) * nq + (slots >> 2)
         Fz = np.zeros((sp + 1, 9))
         Fz[perm] = F.reshape(sp, 9)
-        deg = (nb != ZS).sum(axis=1).astype(np.float64)
+        assert np.array_equal(deg_packed, (nb != ZS).sum(axis=1)), "packed degree must equal the neighbour count"
+        deg = deg_packed.astype(np.float64)
         H = deg[:, None] * F.reshape(sp, 9) - Fz[nb].sum(axis=1)
         H[~owned] = 0.0
         Es += 0.5 * float((H * H).sum())

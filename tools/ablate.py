@@ -77,6 +77,20 @@ def main():
         print(f"mask {mask:3d} {what:50s} tile {row['tile_ms']:.4f} ms  finish {row['finish_ms']:.4f} ms  "
               f"{row['gtets_per_s']:.2f} Gtet/s", flush=True)
     _capi.check(lib.tsamd_debug_set_ablation(ts._handle(), 0))
+    # per-phase shader-clock stamps of thread 0 of every tile
+    import numpy as np
+    clk = np.zeros(16 * info["n_tiles"], dtype=np.int64)
+    _capi.check(lib.tsamd_debug_read_clocks(ts._handle(), clk.ctypes.data, clk.size))      # arm
+    _capi.check(lib.tsamd_forward_backward(ts._handle(), x.data_ptr(), None, 1e-4, 2e-4, 2, stream,
+                                           e.data_ptr(), g.data_ptr()))
+    _capi.check(lib.tsamd_debug_read_clocks(ts._handle(), clk.ctypes.data, clk.size))      # read
+    clk = clk.reshape(-1, 16)[:, :10]
+    names = ["load+stage", "pass1", "pass2", "H write+reload issue", "pass3 (own wave)", "wait others",
+             "force write", "vertex gather+stores", "energy reduce"]
+    d = np.diff(clk, axis=1)
+    out["phase_cycles_mean"] = {n: float(d[:, i].mean()) for i, n in enumerate(names)}
+    print("phase cycles (mean over tiles, thread 0): " +
+          ", ".join(f"{n} {d[:, i].mean():.0f}" for i, n in enumerate(names)) + f", total {(clk[:, 9] - clk[:, 0]).mean():.0f}")
     print(json.dumps(out))
 
 

@@ -80,6 +80,7 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "tsamd_debug_set_ablation": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsamd_debug_read_clocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "tsamd_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -73,6 +73,7 @@ struct tsamd_handle {
     float *d_energy_scratch = nullptr;
     // optional kernel timing (bench.py roofline leg)
     int dbg = 0;  // kernel ablation switches, tools/ablate.py only
+    long long *d_clk = nullptr;  // 16 clock stamps per tile (ablation builds)
     bool timing = false;
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
@@ -105,6 +106,7 @@ void release(tsamd_handle *h)
         (void)hipFree(h->d_partials);
         (void)hipFree(h->d_terms);
         (void)hipFree(h->d_energy_scratch);
+        (void)hipFree(h->d_clk);
         for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     }
     delete h;
@@ -218,6 +220,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
     a.dbg = h->dbg;
+    a.clk = h->d_clk;
     a.x = x;
     a.grad_out = grad_out;
     a.c1 = c1;
@@ -369,6 +372,25 @@ int tsamd_debug_set_ablation(tsamd_handle *h, int flags)
     if (flags) return fail(TSAMD_ERR_INVALID_ARGUMENT, "this build has no ablation switches (compile with -DTSAMD_ABLATION)");
 #endif
     h->dbg = flags;
+    return TSAMD_OK;
+}
+
+int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capacity)
+{
+    if (!h || !host_out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
+    if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
+    const int64_t need = int64_t(h->plan.tiles.size()) * 16;
+    if (capacity < need) return fail(TSAMD_ERR_INVALID_ARGUMENT, "capacity too small: need 16 entries per tile");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    if (!h->d_clk) {   // first call arms the stamps; the next evaluation fills them
+        TSAMD_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_clk), size_t(need) * sizeof(long long)));
+        TSAMD_HIP(hipMemset(h->d_clk, 0, size_t(need) * sizeof(long long)));
+        std::memset(host_out, 0, size_t(need) * sizeof(long long));
+        return TSAMD_OK;
+    }
+    TSAMD_HIP(hipDeviceSynchronize());
+    TSAMD_HIP(hipMemcpy(host_out, h->d_clk, size_t(need) * sizeof(long long), hipMemcpyDeviceToHost));
     return TSAMD_OK;
 }
 

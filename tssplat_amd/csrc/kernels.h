@@ -18,6 +18,7 @@ struct EvalArgs {
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
+    long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
     // per evaluation
     const float *x;
     const float *grad_out;  // device scalar or nullptr

@@ -66,21 +66,17 @@ __device__ __forceinline__ float comp(const float4 &v, int p)
     return p == 0 ? v.x : (p == 1 ? v.y : (p == 2 ? v.z : v.w));
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-    return v;
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-// F of one slot from the staged positions and the slot's Dm^-1 (held in registers)
-__device__ __forceinline__ void slot_F(const float4 *xs, uint32_t lv0, uint32_t lv1, uint32_t lv2, uint32_t lv3,
+// F of one slot from the staged positions (byte offsets o0..o3 into xs) and the slot's Dm^-1.
+// xs holds (x, y, z, 0); reading it as 4 x u32 behind an asm fence keeps the compiler from
+// narrowing the access to ds_read_b96, which costs 8 LDS cycles against 4 for ds_read_b128.
+__device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
                                        const float4 *dm, int p, float *F)
 {
-    // xs holds (x, y, z, 0); reading it as 4 x u32 keeps the compiler from narrowing the access to
-    // ds_read_b96, which costs 8 LDS cycles against 4 for ds_read_b128
-    const v4u r0 = reinterpret_cast<const v4u *>(xs)[lv0], r1 = reinterpret_cast<const v4u *>(xs)[lv1],
-              r2 = reinterpret_cast<const v4u *>(xs)[lv2], r3 = reinterpret_cast<const v4u *>(xs)[lv3];
+    const v4u r0 = *reinterpret_cast<const v4u *>(xs + o0), r1 = *reinterpret_cast<const v4u *>(xs + o1),
+              r2 = *reinterpret_cast<const v4u *>(xs + o2), r3 = *reinterpret_cast<const v4u *>(xs + o3);
     asm volatile("" : : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
     const float3 x0 = make_float3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
     const float3 x1 = make_float3(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
@@ -94,6 +90,45 @@ __device__ __forceinline__ void slot_F(const float4 *xs, uint32_t lv0, uint32_t 
         for (int j = 0; j < 3; ++j)
             F[3 * i + j] = Ds[3 * i + 0] * comp(dm[j], p) + Ds[3 * i + 1] * comp(dm[3 + j], p) +
                            Ds[3 * i + 2] * comp(dm[6 + j], p);
+}
+
+// One 48-byte LDS slot holds F (9 floats, 3 pad), later H, later the 4 x 3 vertex forces.
+struct Mat9 {
+    v2f p01, p23, p45, p67;  // packed pairs: v_pk_{mul,add,fma}_f32 work on these at twice the scalar rate
+    float p8;
+};
+
+__device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx)
+{
+    const unsigned char *s = lds + idx * 48u;
+    const v4f a = *reinterpret_cast<const v4f *>(s), b = *reinterpret_cast<const v4f *>(s + 16);
+    Mat9 m;
+    m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
+    m.p8 = *reinterpret_cast<const float *>(s + 32);
+    return m;
+}
+
+__device__ __forceinline__ void store_slot(unsigned char *lds, uint32_t idx, const float *m)
+{
+    unsigned char *s = lds + idx * 48u;
+    *reinterpret_cast<v4f *>(s) = v4f{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<v4f *>(s + 16) = v4f{m[4], m[5], m[6], m[7]};
+    *reinterpret_cast<float *>(s + 32) = m[8];
+}
+
+// acc = deg * own - sum of the four neighbours (zero slot for a missing one)
+__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, const Mat9 &own, float deg, const uint32_t *nb)
+{
+    Mat9 acc;
+    acc.p01 = own.p01 * deg; acc.p23 = own.p23 * deg; acc.p45 = own.p45 * deg; acc.p67 = own.p67 * deg;
+    acc.p8 = own.p8 * deg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Mat9 g = load_slot(lds, nb[k]);
+        acc.p01 -= g.p01; acc.p23 -= g.p23; acc.p45 -= g.p45; acc.p67 -= g.p67;
+        acc.p8 -= g.p8;
+    }
+    return acc;
 }
 
 struct KernelArgs {
@@ -110,6 +145,7 @@ struct KernelArgs {
     int n_tiles;
     int tiles_per_xcd;
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
+    long long *clk;  // ablation builds: 16 shader-clock stamps per tile (phase boundaries of thread 0)
 };
 
 enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
@@ -117,19 +153,23 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 
 #ifdef TSAMD_ABLATION
 #define DBG(flag) ((a.dbg & (flag)) != 0)
+#define STAMP(k)                                                          \
+    do {                                                                  \
+        if (a.clk && threadIdx.x == 0) a.clk[16 * size_t(tile) + (k)] = clock64(); \
+    } while (0)
 #else
 #define DBG(flag) false
+#define STAMP(k) ((void)0)
 #endif
 
 // One workgroup = one tile.  LDS map (SA = s_pad + 4 slots incl. the all-zero slot at index s_pad,
 // VP = vertices rounded up to 4):
-//   [0, 16 SA)        FA: float4 per slot  (F[0..3], later H, addressed by lds_index(slot))
-//   [16 SA, 32 SA)    FB: float4 per slot  (F[4..7])
-//   [32 SA, 36 SA)    FC: float  per slot  (F[8])
-//   [36 SA, +16 VP)   xs: float4 per local vertex (staged positions)
-//   [0, 48 SA)        DV: 4 planes (one per local tet vertex) of 3 floats per slot -- the per-tet
-//                     vertex forces, written over F/H/xs once those are dead
+//   [0, 48 SA)        one 48 B record per slot, addressed by lds_index(slot): F (9 floats + pad),
+//                     overwritten by H after pass 2, overwritten by the 4 x 3 vertex forces after pass 3
+//   [48 SA, +16 VP)   xs: float4 per local vertex (staged positions)
 //   then 256 B of reduction scratch.
+// Lane t's p-th slot lives at index p * nq + t, so a wave's own-slot accesses walk consecutive
+// 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
 // BLOCK only sets the VGPR budget (1024 threads = 4 waves/SIMD = 128 VGPRs).
 template <bool WITH_GRAD, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
@@ -150,16 +190,12 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     const int VP = (td.n_verts + 3) & ~3;
     const uint32_t ZS = uint32_t(td.s_pad);
 
-    float4 *FA = reinterpret_cast<float4 *>(smem);
-    float4 *FB = FA + SA;
-    float *FC = reinterpret_cast<float *>(FB + SA);
-    float4 *xs = reinterpret_cast<float4 *>(FC + SA);
-    float *DV = reinterpret_cast<float *>(smem);
-    const int lds_main = 36 * SA + 16 * VP > 48 * SA ? 36 * SA + 16 * VP : 48 * SA;
-    double *red = reinterpret_cast<double *>(smem + lds_main);
+    unsigned char *xs = smem + 48 * SA;
+    double *red = reinterpret_cast<double *>(xs + 16 * VP);
 
     const bool active = tid < nq;
     const uint4 *pl = reinterpret_cast<const uint4 *>(a.blob + td.blob_off);
+    STAMP(0);
 
     // ---- stream the tile: 13 coalesced 16 B/lane loads per thread (4 consecutive slots each) ----
     uint4 q_lv01 = make_uint4(0, 0, 0, 0), q_lv23 = q_lv01, q_nb01 = q_lv01, q_nb23 = q_lv01;
@@ -176,16 +212,14 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     // ---- stage the tile's vertex positions ----
     for (int v = tid; v < td.n_verts; v += nthr) {
         const size_t gv = size_t(a.gvid[td.vert_off + v]) * 3;
-        xs[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
+        reinterpret_cast<float4 *>(xs)[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
     }
-    if (tid == 0) {
-        FA[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
-        FB[ZS] = make_float4(0.f, 0.f, 0.f, 0.f);
-        FC[ZS] = 0.f;
-    }
+    if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot
     __syncthreads();
+    STAMP(1);  // planes + positions landed
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
-        float chk = dm[0].x + dm[4].y + dm[8].z + float(q_lv01.x ^ q_lv23.y ^ q_nb01.z ^ q_nb23.w) + xs[tid % td.n_verts].x;
+        float chk = dm[0].x + dm[4].y + dm[8].z + float(q_lv01.x ^ q_lv23.y ^ q_nb01.z ^ q_nb23.w) +
+                    reinterpret_cast<float *>(xs)[tid % td.n_verts];
         if (chk == 12345.678f) a.partials[0] = chk;
         return;
     }
@@ -197,7 +231,6 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
-            const bool owned = (w0 & kOwnedBit) != 0;
             float F[9];
             slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
             const float J = det3(F);
@@ -210,18 +243,16 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 pen = Jm * Jm * Jm * Jm;
                 dpen = -4.f * Jm * Jm * Jm;
             }
-            if (owned) {
+            if (w0 & kOwnedBit) {
                 e_b += pen;
                 scal[p] = a.c2 * dpen;
             }
-            const int s = p * nq + tid;  // lds_index(4 * tid + p)
-            FA[s] = make_float4(F[0], F[1], F[2], F[3]);
-            FB[s] = make_float4(F[4], F[5], F[6], F[7]);
-            FC[s] = F[8];
+            store_slot(smem, uint32_t(p * nq + tid), F);
             SLOT_FENCE();
         }
     }
     __syncthreads();
+    STAMP(2);  // pass 1 done
     if (DBG(DBG_EXIT_AFTER_P1)) {
         if (e_b == 12345.678f) a.partials[0] = e_b;
         return;
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
     // With the balanced slot order, position p of lane t is item p * nq + t and items below n_owned
     // are the owned ones, so `owned` is uniform across all but one wave per position: halo slots
-    // skip their twelve gathers with a real branch.
+    // skip their gathers with a real branch.
     float H[4][9];
     if (active && !DBG(DBG_SKIP_P2)) {
 #pragma unroll
@@ -239,36 +270,34 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
             for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
             if (n01 & kOwnedBit) {
-                uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
-                const int s = p * nq + tid;
-                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(s);
-                const float4 fa = FA[s], fb = FB[s];
-                const float fc = FC[s];
-                const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
-                float acc[9] = {deg * fa.x, deg * fa.y, deg * fa.z, deg * fa.w, deg * fb.x,
-                                deg * fb.y, deg * fb.z, deg * fb.w, deg * fc};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 ga = FA[nb[k]], gb = FB[nb[k]];
-                    const float gc = FC[nb[k]];
-                    acc[0] -= ga.x; acc[1] -= ga.y; acc[2] -= ga.z; acc[3] -= ga.w;
-                    acc[4] -= gb.x; acc[5] -= gb.y; acc[6] -= gb.z; acc[7] -= gb.w;
-                    acc[8] -= gc;
-                }
-                float sq = 0.f;
-#pragma unroll
-                for (int c = 0; c < 9; ++c) {
-                    sq += acc[c] * acc[c];
-                    H[p][c] = acc[c];
-                }
-                e_s += 0.5f * sq;
+                uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
+                const uint32_t so = uint32_t(p * nq + tid);
+                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = so;
+                const Mat9 h = laplace_gather(smem, load_slot(smem, so), float(n01 >> kDegShift), nb);
+                v2f sq = h.p01 * h.p01;
+                sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
+                sq = __builtin_elementwise_fma(h.p45, h.p45, sq);
+                sq = __builtin_elementwise_fma(h.p67, h.p67, sq);
+                e_s += 0.5f * (sq.x + sq.y + h.p8 * h.p8);
+                H[p][0] = h.p01.x; H[p][1] = h.p01.y; H[p][2] = h.p23.x; H[p][3] = h.p23.y;
+                H[p][4] = h.p45.x; H[p][5] = h.p45.y; H[p][6] = h.p67.x; H[p][7] = h.p67.y;
+                H[p][8] = h.p8;
             }
             SLOT_FENCE();  // keep one slot's gathers in flight, not four (VGPR budget)
         }
     }
     __syncthreads();  // every read of F is done; overwrite it with H in place
+    STAMP(3);  // pass 2 done
 
     if (WITH_GRAD) {
+        // vertex incidence lists (thread t gathers local vertex t): fetch the first kPre chunks now so
+        // that their HBM latency hides behind pass 3
+        constexpr int kPre = 6;
+        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
+        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
+        const uint32_t pad16 = (ZS << 2) | 1u;
+        int pc0 = 0, pc1 = 0;
+        uint2 pre[kPre];
         if (active) {
             // Dm^-1 and the vertex ids are needed again by pass 3.  Re-issuing their 11 loads here
             // instead of pinning 44 VGPRs across pass 2 keeps the kernel inside 128 VGPRs
@@ -279,41 +308,27 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
             for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int s = p * nq + tid;
-                FA[s] = make_float4(H[p][0], H[p][1], H[p][2], H[p][3]);
-                FB[s] = make_float4(H[p][4], H[p][5], H[p][6], H[p][7]);
-                FC[s] = H[p][8];
-            }
+            for (int p = 0; p < 4; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
         }
         __syncthreads();
+        STAMP(4);  // H written, reloads issued
 
         // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T (per-tet vertex forces) ----
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
-        // Held in registers across the barrier, then written over F/H/xs (all dead by then).
+        // Held in registers across the barrier, then written over H (all reads of it done by then).
         float D[4][9];
         if (active && !DBG(DBG_SKIP_P3)) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
-                uint32_t nb[4] = {n01 & 0x7fffu, n01 >> 16, n23 & 0xffffu, n23 >> 16};
-                const float deg = float(int(nb[0] != ZS) + int(nb[1] != ZS) + int(nb[2] != ZS) + int(nb[3] != ZS));
-                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = uint32_t(p * nq + tid);
+                uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
+                const uint32_t so = uint32_t(p * nq + tid);
+                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = so;
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
-                const int so = p * nq + tid;
-                const float4 ha = FA[so], hb = FB[so];
-                float P[9] = {deg * ha.x, deg * ha.y, deg * ha.z, deg * ha.w, deg * hb.x,
-                              deg * hb.y, deg * hb.z, deg * hb.w, deg * FC[so]};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 ga = FA[nb[k]], gb = FB[nb[k]];
-                    const float gc = FC[nb[k]];
-                    P[0] -= ga.x; P[1] -= ga.y; P[2] -= ga.z; P[3] -= ga.w;
-                    P[4] -= gb.x; P[5] -= gb.y; P[6] -= gb.z; P[7] -= gb.w;
-                    P[8] -= gc;
-                }
-#pragma unroll
-                for (int c = 0; c < 9; ++c) P[c] *= a.c1;
+                Mat9 q = laplace_gather(smem, load_slot(smem, so), float(n01 >> kDegShift), nb);
+                q.p01 *= a.c1; q.p23 *= a.c1; q.p45 *= a.c1; q.p67 *= a.c1;
+                q.p8 *= a.c1;
+                float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
                     const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
                     float F[9], C[9];
@@ -336,63 +351,57 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
-        // prefetch this thread's vertex incidence chunks (thread t gathers local vertex t) so their
-        // HBM latency hides behind the barriers and the d write
-        constexpr int kPre = 6;
-        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
-        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
-        int pc0 = 0, pc1 = 0;
-        uint2 pre[kPre];
         if (tid < td.n_verts) {
             pc0 = inc_off[tid];
             pc1 = inc_off[tid + 1];
 #pragma unroll
-            for (int q = 0; q < kPre; ++q) pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : make_uint2(0u, 0u);
+            for (int q = 0; q < kPre; ++q)
+                pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : make_uint2(pad16 * 0x10001u, pad16 * 0x10001u);
         }
+        STAMP(5);  // pass 3 compute done (this wave)
         __syncthreads();
-        // ---- write the vertex forces: plane a holds (fx, fy, fz) of local vertex a for every slot ----
-        const int plane = 3 * SA;  // floats per plane
+        STAMP(6);  // all waves done with H
+        // ---- write the vertex forces: record = (f0.xyz, f1.xyz, f2.xyz, f3.xyz), f0 = -(f1 + f2 + f3) ----
         if (active) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                float *d0 = DV + 3 * (p * nq + tid);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    d0[i] = -(D[p][i] + D[p][3 + i] + D[p][6 + i]);
-                    d0[plane + i] = D[p][i];
-                    d0[2 * plane + i] = D[p][3 + i];
-                    d0[3 * plane + i] = D[p][6 + i];
-                }
+                unsigned char *r = smem + uint32_t(p * nq + tid) * 48u;
+                const float *d = D[p];
+                *reinterpret_cast<v4f *>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
+                *reinterpret_cast<v4f *>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
+                *reinterpret_cast<v4f *>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
             }
         }
-        if (tid < 12) DV[(tid / 3) * plane + 3 * ZS + tid % 3] = 0.f;  // the zero slot of every plane
         __syncthreads();
+        STAMP(7);  // vertex forces written
 
         // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
-        // Entry = (lds slot << 2) | local vertex; its force sits at DV[a * plane + 3 * slot].
-        // Exclusive vertices go straight to grad, vertices shared with other tiles to the staging rows.
-        // (The first kPre chunks of this thread's first vertex were prefetched before the barriers.)
+        // Entry e = (lds slot << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
+        // point into the all-zero slot.  Exclusive vertices go straight to grad, vertices shared with
+        // other tiles to the staging rows, which the finish kernel sums in plan order.
         const float gscale = a.grad_out ? *a.grad_out : 1.f;
         for (int v = tid; v < td.n_verts; v += nthr) {
-            const int c0 = v == tid ? pc0 : int(inc_off[v]), c1 = v == tid ? pc1 : int(inc_off[v + 1]);
             float gx = 0.f, gy = 0.f, gz = 0.f;
             auto gather4 = [&](const uint2 w) {
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float *f = DV + (ent[q] & 3u) * plane + 3 * (ent[q] >> 2);
+                    const float *f = reinterpret_cast<const float *>(smem + ent[q] * 12u);
                     gx += f[0];
                     gy += f[1];
                     gz += f[2];
                 }
             };
             if (!DBG(DBG_SKIP_VGATHER)) {
-                int c = c0;
-                if (v == tid) {
+                int c, c1;
+                if (v == tid) {  // prefetched chunks; the ones past the list end are all-padding
 #pragma unroll
-                    for (int q = 0; q < kPre; ++q)
-                        if (c0 + q < c1) gather4(pre[q]);
-                    c = c0 + kPre;
+                    for (int q = 0; q < kPre; ++q) gather4(pre[q]);
+                    c = pc0 + kPre;
+                    c1 = pc1;
+                } else {
+                    c = inc_off[v];
+                    c1 = inc_off[v + 1];
                 }
                 for (; c < c1; ++c) gather4(inc[c]);
             }
@@ -409,12 +418,17 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         }
     }
 
-    // ---- deterministic block reduction of the two energy terms (fixed order, double) ----
-    double ds = wave_sum(double(e_s)), db = wave_sum(double(e_b));
+    STAMP(8);  // vertex gather + stores done (this wave)
+    // ---- deterministic block reduction of the two energy terms (fixed order; doubles across waves) ----
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        e_s += __shfl_down(e_s, off, kWave);
+        e_b += __shfl_down(e_b, off, kWave);
+    }
     const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
     if (lane == 0) {
-        red[2 * wave] = ds;
-        red[2 * wave + 1] = db;
+        red[2 * wave] = double(e_s);
+        red[2 * wave + 1] = double(e_b);
     }
     __syncthreads();
     if (tid == 0) {
@@ -426,6 +440,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         a.partials[2 * size_t(tile)] = s;
         a.partials[2 * size_t(tile) + 1] = b;
     }
+    STAMP(9);
 }
 
 struct FinishArgs {
@@ -586,6 +601,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.n_tiles = int(e.n_tiles);
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.dbg = e.dbg;
+        k.clk = e.clk;
         const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
         const bool small = false;  // the 768-thread instantiation (168 VGPRs) schedules worse and spills more; unused
         if (e.grad && small)

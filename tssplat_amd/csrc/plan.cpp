@@ -150,7 +150,7 @@ struct Limits {
     bool fits(int64_t n_slots, int64_t n_verts) const
     {
         const int64_t sp = (n_slots + 3) & ~int64_t(3);
-        return sp <= max_spad && n_verts <= 32767 && tile_lds_bytes(sp, n_verts) <= budget;
+        return sp <= max_spad && n_verts <= kMaxTileVerts && tile_lds_bytes(sp, n_verts) <= budget;
     }
 };
 
@@ -308,7 +308,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 160 * 1024;
-    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 16380);  // (slot << 2 | a) must fit 16 bits
+    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 8188);  // slot ids are 13-bit fields
     if (lim.budget < tile_lds_bytes(8, 8)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
@@ -413,8 +413,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             c = ce;
         }
     }
-    // LDS per slot: max(36 B + 16 B per vertex at ~0.27 vertices per slot, 48 B of vertex forces)
-    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / 48);
+    // LDS: 48 B per slot + 16 B per vertex at ~0.27 vertices per slot
+    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / 53);
     int64_t target = opt.target_owned > 0 ? opt.target_owned : int64_t(0.70 * double(s_cap));
     target = std::max<int64_t>(1, target);
 
@@ -594,8 +594,10 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 const bool owned = L < d.n_owned;
                 stet[s] = el;
                 uint32_t lv[4], nb[4];
-                for (int a = 0; a < 4; ++a) lv[a] = uint32_t(S.vert_local[tets[4 * int64_t(el) + a]]);
+                // local vertices as byte offsets into the staged float4 positions (16 B each)
+                for (int a = 0; a < 4; ++a) lv[a] = uint32_t(S.vert_local[tets[4 * int64_t(el) + a]]) << 4;
                 if (owned) lv[0] |= kOwnedBit;
+                uint32_t deg = 0;
                 for (int k = 0; k < 4; ++k) {
                     int32_t q = P.nbr[4 * size_t(el) + k];
                     uint32_t v = ZS;
@@ -608,10 +610,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         }
                     }
                     nb[k] = v;
+                    deg += v != ZS;
                 }
                 pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
                 pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
-                pl[2 * size_t(d.s_pad) + s] = nb[0] | (owned ? kOwnedBit : 0u) | (nb[1] << 16);
+                pl[2 * size_t(d.s_pad) + s] = nb[0] | (owned ? kOwnedBit : 0u) | (nb[1] << 16) | (deg << kDegShift);
                 pl[3 * size_t(d.s_pad) + s] = nb[2] | (nb[3] << 16);
                 // Dm^-1 in double from the fp32 rest positions, rounded to fp32
                 const int32_t *tt = tets + 4 * int64_t(el);

@@ -44,7 +44,15 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI
 //                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
 //   n_verts + 1 x u16         : first chunk of every local vertex
 constexpr int kPlanes = 13;
+// Index planes, two 16-bit fields per dword:
+//   lv01 = (16 * v0 | owned << 15) | (16 * v1) << 16      vertex ids pre-multiplied to byte offsets
+//   lv23 = (16 * v2)               | (16 * v3) << 16      into the staged float4 positions
+//   nb01 = (n0 | owned << 15)      | (n1 | deg << 13) << 16   n = LDS slot index of the face neighbour
+//   nb23 =  n2                     |  n3 << 16                (s_pad = the all-zero slot), deg = #neighbours
 constexpr uint32_t kOwnedBit = 0x8000u;
+constexpr int kDegShift = 29;
+constexpr uint32_t kSlotMask = 0x1fffu;
+constexpr int kMaxTileVerts = 2047;
 
 // Where slot s (HBM plane order: thread t streams slots 4t..4t+3 as one 16 B load per plane) lives in
 // the LDS planes.  Lane t keeps its p-th slot at p * nq + t, so the 64 lanes of a wave touch 64
@@ -52,14 +60,14 @@ constexpr uint32_t kOwnedBit = 0x8000u;
 // 70 % of all LDS cycles).  Neighbour and incidence entries in the blob hold these LDS indices.
 inline int32_t lds_index(int32_t slot, int32_t nq) { return (slot & 3) * nq + (slot >> 2); }
 
-// LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices.
+// LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices:
+// 48 B per slot (F as 9 floats + 3 pad, later H, later the 4 x 3 vertex forces), + the zero slot,
+// 16 B per staged vertex position, 256 B of reduction scratch.
 inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts)
 {
-    const int64_t sa = s_pad + 4;                 // + the all-zero slot, kept 16 B aligned
+    const int64_t sa = s_pad + 4;
     const int64_t vp = (n_verts + 3) & ~int64_t(3);
-    const int64_t fx = 36 * sa + 16 * vp;         // F / H planes + staged positions (float4)
-    const int64_t dv = 48 * sa;                   // 4 planes of per-vertex forces, aliasing the above
-    return (fx > dv ? fx : dv) + 256;             // + reduction scratch
+    return 48 * sa + 16 * vp + 256;
 }
 
 struct Plan {
