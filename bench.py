@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--max-threads", type=int, default=0)
     p.add_argument("--lds-budget", type=int, default=0)
     p.add_argument("--target-owned", type=int, default=0)
+    p.add_argument("--spt", type=int, default=0, help="slots per thread (2 or 4; 0 = library default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-spheres", type=int, default=8)
     return p.parse_args()
@@ -134,7 +135,8 @@ def main():
 
     t0 = time.time()
     energy = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, max_threads=args.max_threads,
-                                     lds_budget_bytes=args.lds_budget, target_owned=args.target_owned)
+                                     lds_budget_bytes=args.lds_budget, target_owned=args.target_owned,
+                                     slots_per_thread=args.spt)
     t_plan = time.time() - t0
     info = energy.tet_sp.plan_info()
     if rank == 0:

@@ -63,6 +63,7 @@ typedef struct tsamd_options {
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
     int32_t debug_shuffle;     /* experiment: spread a tile's tets over lanes instead of Morton order */
+    int32_t slots_per_thread;  /* tets streamed per lane: 4 (16 B loads, default) or 2 (8 B loads, more waves) */
 } tsamd_options;
 
 /* Introspection of the tiling plan (host side; valid for host_only handles too). */
@@ -76,6 +77,7 @@ typedef struct tsamd_plan_info {
     int64_t finish_vertices;     /* global vertices written by the finish kernel                    */
     int64_t device_bytes;        /* bytes of plan data resident in HBM                              */
     int32_t max_slots, max_tile_vertices, block_threads, lds_bytes;
+    int32_t slots_per_thread, reserved;
 } tsamd_plan_info;
 
 /* One tile of the plan, as host pointers into the handle (valid until tsamd_destroy).

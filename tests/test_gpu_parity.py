@@ -76,7 +76,8 @@ def test_config2_64_spheres(ext, sigma, order):
     _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / 64 * mult, 2e-4 * mult, order, label=f"kuhn8x64 s={sigma} p={order}")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(max_threads=768), dict(balance_slots=False), dict(lds_budget_bytes=65536)])
+@pytest.mark.parametrize("kw", [dict(), dict(max_threads=768), dict(balance_slots=False), dict(lds_budget_bytes=65536),
+                                dict(slots_per_thread=2), dict(slots_per_thread=2, max_threads=768, lds_budget_bytes=81920)])
 @pytest.mark.parametrize("sigma,order", [(0.02, 2), (0.3, 4)])
 def test_multi_tile_hires(ext, kw, sigma, order):
     """kuhn_ball(19) spheres need ~16 tiles each: halo slots, staged shared vertices, finish kernel."""

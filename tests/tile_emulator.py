@@ -118,9 +118,10 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         scal = np.where(owned, c2 * dpen, 0.0)
         # LDS planes are addressed by lds_index(slot) = (slot & 3) * nq + (slot >> 2); neighbour and
         # incidence entries hold those indices, the zero slot sits at index s_pad
-        nq = sp // 4
+        spt = info["slots_per_thread"]
+        nq = sp // spt
         slots = np.arange(sp)
-        perm = (slots & 3) * nq + (slots >> 2)
+        perm = (slots % spt) * nq + slots // spt
         Fz = np.zeros((sp + 1, 9))
         Fz[perm] = F.reshape(sp, 9)
         assert np.array_equal(deg_packed, (nb != ZS).sum(axis=1)), "packed degree must equal the neighbour count"

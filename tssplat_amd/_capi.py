@@ -34,6 +34,7 @@ class Options(C.Structure):
         ("host_only", C.c_int32),
         ("num_threads", C.c_int32),
         ("debug_shuffle", C.c_int32),
+        ("slots_per_thread", C.c_int32),
     ]
 
 
@@ -43,7 +44,7 @@ class PlanInfo(C.Structure):
         ("n_components", C.c_int64), ("total_slots", C.c_int64), ("total_tile_vertices", C.c_int64),
         ("shared_vertex_copies", C.c_int64), ("finish_vertices", C.c_int64), ("device_bytes", C.c_int64),
         ("max_slots", C.c_int32), ("max_tile_vertices", C.c_int32), ("block_threads", C.c_int32),
-        ("lds_bytes", C.c_int32),
+        ("lds_bytes", C.c_int32), ("slots_per_thread", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

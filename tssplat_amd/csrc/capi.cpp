@@ -166,6 +166,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.balance = opt.balance_slots;
     po.num_threads = opt.num_threads;
     po.shuffle = opt.debug_shuffle;
+    if (opt.slots_per_thread) po.slots_per_thread = opt.slots_per_thread;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;
@@ -219,6 +220,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.n_finish = int64_t(h->plan.fin_vid.size());
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
+    a.spt = h->plan.spt;
     a.dbg = h->dbg;
     a.clk = h->d_clk;
     a.x = x;
@@ -289,6 +291,7 @@ int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out)
     out->max_tile_vertices = P.max_verts;
     out->block_threads = P.block_threads;
     out->lds_bytes = P.lds_bytes;
+    out->slots_per_thread = P.spt;
     return TSAMD_OK;
 }
 

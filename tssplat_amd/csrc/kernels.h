@@ -17,6 +17,7 @@ struct EvalArgs {
     const int32_t *fin_vid, *fin_off, *fin_idx;
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
+    int32_t spt = 4;        // slots per thread the plan was laid out for
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
     long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
     // per evaluation

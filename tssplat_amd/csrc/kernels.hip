@@ -57,23 +57,15 @@ __device__ __forceinline__ void cof3(const float *F, float *C)
     C[8] = F[0] * F[4] - F[1] * F[3];
 }
 
-__device__ __forceinline__ uint32_t comp(const uint4 &v, int p)
-{
-    return p == 0 ? v.x : (p == 1 ? v.y : (p == 2 ? v.z : v.w));
-}
-__device__ __forceinline__ float comp(const float4 &v, int p)
-{
-    return p == 0 ? v.x : (p == 1 ? v.y : (p == 2 ? v.z : v.w));
-}
-
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // F of one slot from the staged positions (byte offsets o0..o3 into xs) and the slot's Dm^-1.
 // xs holds (x, y, z, 0); reading it as 4 x u32 behind an asm fence keeps the compiler from
 // narrowing the access to ds_read_b96, which costs 8 LDS cycles against 4 for ds_read_b128.
+template <class VF>
 __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
-                                       const float4 *dm, int p, float *F)
+                                       const VF *dm, int p, float *F)
 {
     const v4u r0 = *reinterpret_cast<const v4u *>(xs + o0), r1 = *reinterpret_cast<const v4u *>(xs + o1),
               r2 = *reinterpret_cast<const v4u *>(xs + o2), r3 = *reinterpret_cast<const v4u *>(xs + o3);
@@ -88,8 +80,7 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            F[3 * i + j] = Ds[3 * i + 0] * comp(dm[j], p) + Ds[3 * i + 1] * comp(dm[3 + j], p) +
-                           Ds[3 * i + 2] * comp(dm[6 + j], p);
+            F[3 * i + j] = Ds[3 * i + 0] * dm[j][p] + Ds[3 * i + 1] * dm[3 + j][p] + Ds[3 * i + 2] * dm[6 + j][p];
 }
 
 // One 48-byte LDS slot holds F (9 floats, 3 pad), later H, later the 4 x 3 vertex forces.
@@ -170,10 +161,13 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 //   then 256 B of reduction scratch.
 // Lane t's p-th slot lives at index p * nq + t, so a wave's own-slot accesses walk consecutive
 // 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
-// BLOCK only sets the VGPR budget (1024 threads = 4 waves/SIMD = 128 VGPRs).
-template <bool WITH_GRAD, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
+// SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
+// SIMD): <1024, 4> gives 128 VGPRs and one workgroup per CU, <768, 6> 80 VGPRs and two.
+template <bool WITH_GRAD, int BLOCK, int SPT, int WPE>
+__global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
+    typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
+    typedef float VF __attribute__((ext_vector_type(SPT)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
@@ -185,7 +179,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
 
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int nq = td.s_pad >> 2;
+    const int nq = td.s_pad / SPT;
     const int SA = td.s_pad + 4;
     const int VP = (td.n_verts + 3) & ~3;
     const uint32_t ZS = uint32_t(td.s_pad);
@@ -194,20 +188,21 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     double *red = reinterpret_cast<double *>(xs + 16 * VP);
 
     const bool active = tid < nq;
-    const uint4 *pl = reinterpret_cast<const uint4 *>(a.blob + td.blob_off);
+    const uint32_t *pl = reinterpret_cast<const uint32_t *>(a.blob + td.blob_off);  // 13 planes of s_pad dwords
     STAMP(0);
 
-    // ---- stream the tile: 13 coalesced 16 B/lane loads per thread (4 consecutive slots each) ----
-    uint4 q_lv01 = make_uint4(0, 0, 0, 0), q_lv23 = q_lv01, q_nb01 = q_lv01, q_nb23 = q_lv01;
-    float4 dm[9];
+    // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
+    VU q_lv01 = 0, q_lv23 = 0, q_nb01 = 0, q_nb23 = 0;
+    VF dm[9];
+    auto plane_u = [&](int q) { return *reinterpret_cast<const VU *>(pl + q * td.s_pad + SPT * tid); };
+    auto plane_f = [&](int q) { return *reinterpret_cast<const VF *>(pl + q * td.s_pad + SPT * tid); };
     if (active) {
-        q_lv01 = pl[0 * nq + tid];
-        q_lv23 = pl[1 * nq + tid];
-        q_nb01 = pl[2 * nq + tid];
-        q_nb23 = pl[3 * nq + tid];
-        const float4 *dpl = reinterpret_cast<const float4 *>(pl + 4 * nq);
+        q_lv01 = plane_u(0);
+        q_lv23 = plane_u(1);
+        q_nb01 = plane_u(2);
+        q_nb23 = plane_u(3);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
+        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     }
     // ---- stage the tile's vertex positions ----
     for (int v = tid; v < td.n_verts; v += nthr) {
@@ -218,19 +213,21 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     __syncthreads();
     STAMP(1);  // planes + positions landed
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
-        float chk = dm[0].x + dm[4].y + dm[8].z + float(q_lv01.x ^ q_lv23.y ^ q_nb01.z ^ q_nb23.w) +
+        float chk = dm[0][0] + dm[4][1] + dm[8][SPT - 1] + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
                     reinterpret_cast<float *>(xs)[tid % td.n_verts];
         if (chk == 12345.678f) a.partials[0] = chk;
         return;
     }
 
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
-    float scal[4] = {0.f, 0.f, 0.f, 0.f};  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
+    float scal[SPT];  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
+#pragma unroll
+    for (int p = 0; p < SPT; ++p) scal[p] = 0.f;
     float e_b = 0.f, e_s = 0.f;
     if (active) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
+        for (int p = 0; p < SPT; ++p) {
+            const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
             float F[9];
             slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
             const float J = det3(F);
@@ -262,11 +259,11 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
     // With the balanced slot order, position p of lane t is item p * nq + t and items below n_owned
     // are the owned ones, so `owned` is uniform across all but one wave per position: halo slots
     // skip their gathers with a real branch.
-    float H[4][9];
+    float H[SPT][9];
     if (active && !DBG(DBG_SKIP_P2)) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
+        for (int p = 0; p < SPT; ++p) {
+            const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
 #pragma unroll
             for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
             if (n01 & kOwnedBit) {
@@ -293,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         // vertex incidence lists (thread t gathers local vertex t): fetch the first kPre chunks now so
         // that their HBM latency hides behind pass 3
         constexpr int kPre = 6;
-        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * nq);
+        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * td.s_pad);
         const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
         const uint32_t pad16 = (ZS << 2) | 1u;
         int pc0 = 0, pc1 = 0;
@@ -302,13 +299,12 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
             // Dm^-1 and the vertex ids are needed again by pass 3.  Re-issuing their 11 loads here
             // instead of pinning 44 VGPRs across pass 2 keeps the kernel inside 128 VGPRs
             // (16 waves/CU) without scratch spills.
-            q_lv01 = pl[0 * nq + tid];
-            q_lv23 = pl[1 * nq + tid];
-            const float4 *dpl = reinterpret_cast<const float4 *>(pl + 4 * nq);
+            q_lv01 = plane_u(0);
+            q_lv23 = plane_u(1);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) dm[c] = dpl[c * nq + tid];
+            for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
 #pragma unroll
-            for (int p = 0; p < 4; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
+            for (int p = 0; p < SPT; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
         }
         __syncthreads();
         STAMP(4);  // H written, reloads issued
@@ -316,11 +312,11 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T (per-tet vertex forces) ----
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
         // Held in registers across the barrier, then written over H (all reads of it done by then).
-        float D[4][9];
+        float D[SPT][9];
         if (active && !DBG(DBG_SKIP_P3)) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t n01 = comp(q_nb01, p), n23 = comp(q_nb23, p);
+            for (int p = 0; p < SPT; ++p) {
+                const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
                 uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
                 const uint32_t so = uint32_t(p * nq + tid);
                 if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = so;
@@ -330,7 +326,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 q.p8 *= a.c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    const uint32_t w0 = comp(q_lv01, p), w1 = comp(q_lv23, p);
+                    const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
                     slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
                     cof3(F, C);
@@ -341,13 +337,13 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
                     for (int i = 0; i < 3; ++i)
-                        D[p][3 * k + i] = P[3 * i + 0] * comp(dm[3 * k + 0], p) + P[3 * i + 1] * comp(dm[3 * k + 1], p) +
-                                          P[3 * i + 2] * comp(dm[3 * k + 2], p);
+                        D[p][3 * k + i] = P[3 * i + 0] * dm[3 * k + 0][p] + P[3 * i + 1] * dm[3 * k + 1][p] +
+                                          P[3 * i + 2] * dm[3 * k + 2][p];
                 SLOT_FENCE();
             }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < SPT; ++p)
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
@@ -364,7 +360,7 @@ __global__ __launch_bounds__(BLOCK) void tile_energy_kernel(const KernelArgs a)
         // ---- write the vertex forces: record = (f0.xyz, f1.xyz, f2.xyz, f3.xyz), f0 = -(f1 + f2 + f3) ----
         if (active) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
+            for (int p = 0; p < SPT; ++p) {
                 unsigned char *r = smem + uint32_t(p * nq + tid) * 48u;
                 const float *d = D[p];
                 *reinterpret_cast<v4f *>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
@@ -561,10 +557,12 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
 
 hipError_t configure_kernels(int lds_bytes)
 {
-    const void *fns[4] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024>),
-                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024>),
-                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 768>),
-                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 768>)};
+    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -603,15 +601,18 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.dbg = e.dbg;
         k.clk = e.clk;
         const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
-        const bool small = false;  // the 768-thread instantiation (168 VGPRs) schedules worse and spills more; unused
-        if (e.grad && small)
-            hipLaunchKernelGGL((tile_energy_kernel<true, 768>), grid, block, size_t(e.lds_bytes), stream, k);
-        else if (e.grad)
-            hipLaunchKernelGGL((tile_energy_kernel<true, 1024>), grid, block, size_t(e.lds_bytes), stream, k);
-        else if (small)
-            hipLaunchKernelGGL((tile_energy_kernel<false, 768>), grid, block, size_t(e.lds_bytes), stream, k);
-        else
-            hipLaunchKernelGGL((tile_energy_kernel<false, 1024>), grid, block, size_t(e.lds_bytes), stream, k);
+        // 2 slots per lane and two workgroups per CU (<= 80 KiB LDS, <= 768 threads): the 80-VGPR build
+        const bool two_per_cu = e.spt == 2 && e.block_threads <= 768 && e.lds_bytes <= 80 * 1024;
+#define TSAMD_LAUNCH(G, B, S, W) \
+    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(e.lds_bytes), stream, k)
+        if (e.spt == 2 && two_per_cu) {
+            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
+        } else if (e.spt == 2) {
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4); else TSAMD_LAUNCH(false, 1024, 2, 4);
+        } else {
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4); else TSAMD_LAUNCH(false, 1024, 4, 4);
+        }
+#undef TSAMD_LAUNCH
         hipError_t err = hipGetLastError();
         if (err != hipSuccess) return err;
     }

@@ -308,7 +308,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 160 * 1024;
-    lim.max_spad = std::min<int64_t>(4 * int64_t(max_threads), 8188);  // slot ids are 13-bit fields
+    const int spt = opt.slots_per_thread == 2 ? 2 : 4;
+    lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 8188);  // slot ids are 13-bit fields
     if (lim.budget < tile_lds_bytes(8, 8)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
@@ -317,6 +318,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     P = Plan();
     P.n = n;
     P.m = m;
+    P.spt = spt;
     int rc = build_adjacency(tets, n, m, P.nbr, nthreads, err);
     if (rc) return rc;
     Mesh M{rest, tets, P.nbr.data(), n, m};
@@ -532,7 +534,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         P.max_slots = std::max(P.max_slots, d.n_slots);
         P.max_verts = std::max(P.max_verts, d.n_verts);
         P.lds_bytes = std::max<int32_t>(P.lds_bytes, int32_t(tile_lds_bytes(d.s_pad, d.n_verts)));
-        max_quads = std::max(max_quads, d.s_pad / 4);
+        max_quads = std::max(max_quads, d.s_pad / spt);
         if (vert_off >= (int64_t(1) << 31)) {
             err = "too many tile vertices for 32-bit offsets";
             return ERR_TILING;
@@ -562,7 +564,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 S.vert_local[tv[size_t(i)]] = i;
                 P.gvid[size_t(d.vert_off) + size_t(i)] = tv[size_t(i)];
             }
-            const int32_t nq = d.s_pad / 4;
+            const int32_t nq = d.s_pad / spt;
             // shuffle: item L -> item (L * stride) mod n_slots with an odd-ish stride coprime to n_slots, so
             // that the lanes of one wave hold tets that are far apart (no shared vertices)
             int64_t stride = 1;
@@ -572,7 +574,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             }
             auto slot_of_item = [&](int32_t L0) {
                 const int32_t L = opt.shuffle ? int32_t((int64_t(L0) * stride) % d.n_slots) : L0;
-                return balance ? 4 * (L % nq) + L / nq : L;
+                return balance ? spt * (L % nq) + L / nq : L;
             };
             auto item_tet = [&](int32_t L) { return L < d.n_owned ? own[size_t(L)] : halo[size_t(L - d.n_owned)]; };
             for (int32_t L = 0; L < d.n_slots; ++L) {
@@ -604,9 +606,9 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     if (q >= 0) {
                         int32_t qs = S.tet_stamp[q];
                         if (owned) {
-                            v = uint32_t(lds_index(S.tet_slot[q], nq));  // by construction q is owned or halo here
+                            v = uint32_t(lds_index(S.tet_slot[q], nq, spt));  // by construction q is owned or halo here
                         } else if (qs == st) {
-                            v = uint32_t(lds_index(S.tet_slot[q], nq));  // halo tets only look at owned neighbours
+                            v = uint32_t(lds_index(S.tet_slot[q], nq, spt));  // halo tets only look at owned neighbours
                         }
                     }
                     nb[k] = v;
@@ -666,7 +668,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     if (stet[sl] < 0) continue;
                     for (int a = 0; a < 4; ++a) {
                         int32_t v = S.vert_local[tets[4 * int64_t(stet[sl]) + a]];
-                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq)) << 2) | uint32_t(a));
+                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq, spt)) << 2) | uint32_t(a));
                     }
                 }
             }

@@ -21,6 +21,7 @@ struct PlanOptions {
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
     int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
+    int slots_per_thread = 4;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
@@ -54,11 +55,11 @@ constexpr int kDegShift = 29;
 constexpr uint32_t kSlotMask = 0x1fffu;
 constexpr int kMaxTileVerts = 2047;
 
-// Where slot s (HBM plane order: thread t streams slots 4t..4t+3 as one 16 B load per plane) lives in
+// Where slot s (HBM plane order: thread t streams slots spt*t .. spt*t+spt-1 as one load per plane) lives in
 // the LDS planes.  Lane t keeps its p-th slot at p * nq + t, so the 64 lanes of a wave touch 64
 // consecutive float4 -- conflict-free -- instead of a 64 B stride (4-way bank conflict, measured:
 // 70 % of all LDS cycles).  Neighbour and incidence entries in the blob hold these LDS indices.
-inline int32_t lds_index(int32_t slot, int32_t nq) { return (slot & 3) * nq + (slot >> 2); }
+inline int32_t lds_index(int32_t slot, int32_t nq, int32_t spt) { return (slot % spt) * nq + slot / spt; }
 
 // LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices:
 // 48 B per slot (F as 9 floats + 3 pad, later H, later the 4 x 3 vertex forces), + the zero slot,
@@ -82,7 +83,7 @@ struct Plan {
     std::vector<int32_t> fin_vid, fin_off, fin_idx;
     int64_t n_stage = 0;             // rows in the staging buffer
     int64_t total_slots = 0, total_tile_verts = 0;
-    int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0;
+    int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0, spt = 4;
 };
 
 // Returns 0 on success, otherwise a tsamd_status value with `err` filled in.

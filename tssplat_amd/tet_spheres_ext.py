@@ -67,7 +67,8 @@ class TetSpheres:
 
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
-                 balance_slots: bool = True, num_threads: int = 0, debug_shuffle: bool = False):
+                 balance_slots: bool = True, num_threads: int = 0, debug_shuffle: bool = False,
+                 slots_per_thread: int = 0):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
         self._cache = None
@@ -88,7 +89,7 @@ class TetSpheres:
                                   host_only=int(host_only), lds_budget_bytes=lds_budget_bytes,
                                   max_threads=max_threads, target_owned=target_owned,
                                   balance_slots=int(balance_slots), num_threads=num_threads,
-                                  debug_shuffle=int(debug_shuffle))
+                                  debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread)
         if isinstance(vertices, (str, os.PathLike)) and elements is None:
             rc = _lib.tsamd_create_from_veg(os.fspath(vertices).encode(), C.byref(opts), C.byref(self._h))
             _capi.check(rc)
