@@ -56,14 +56,14 @@ typedef enum tsamd_status {
 typedef struct tsamd_options {
     int32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
-    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 163840 (all of a gfx950 CU) */
-    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 1024                      */
+    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU) */
+    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 768                       */
     int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto            */
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
     int32_t debug_shuffle;     /* experiment: spread a tile's tets over lanes instead of Morton order */
-    int32_t slots_per_thread;  /* tets streamed per lane: 4 (16 B loads, default) or 2 (8 B loads, more waves) */
+    int32_t slots_per_thread;  /* tets streamed per lane: 2 (8 B loads, default) or 4 (16 B loads)  */
 } tsamd_options;
 
 /* Introspection of the tiling plan (host side; valid for host_only handles too). */
@@ -111,7 +111,8 @@ int64_t tsamd_num_vertices(const tsamd_handle *h);
 int64_t tsamd_num_tets(const tsamd_handle *h);
 int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out);
 int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out);
-/* finish lists: vertex k (global id vid[k]) = sum of stage rows idx[off[k] .. off[k+1]) */
+/* finish lists: vertex k (global id vid[k]) = sum of staging rows [off[k], off[k+1]);
+ * idx[tile.stage_off + j] = the staging row the tile's j-th shared vertex writes (off[n_finish] entries) */
 int tsamd_get_finish_lists(const tsamd_handle *h, int64_t *n_finish, const int32_t **vid,
                            const int32_t **off, const int32_t **idx);
 /* face adjacency computed at create time: 4 ints per tet, -1 = boundary face */

@@ -66,18 +66,20 @@ def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0,
 @pytest.mark.parametrize("sigma", [0.0, 0.02, 0.3])
 @pytest.mark.parametrize("order", [2, 4])
 def test_config2_64_spheres(ext, sigma, order):
-    """BASELINE config 2: 64 x kuhn_ball(8) = 196 608 tets, one tile per sphere, no halo."""
+    """BASELINE config 2: 64 x kuhn_ball(8) = 196 608 tets."""
     from tssplat_amd import scenes
     sc = scenes.make_scene("kuhn8", 64)
     ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
-    assert ts.plan_info()["n_tiles"] == 64
+    assert ts.plan_info()["n_tiles"] >= 64
     x = scenes.deform(sc, sigma)
     mult = 16.0 if order == 4 else 1.0
     _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / 64 * mult, 2e-4 * mult, order, label=f"kuhn8x64 s={sigma} p={order}")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(max_threads=768), dict(balance_slots=False), dict(lds_budget_bytes=65536),
-                                dict(slots_per_thread=2), dict(slots_per_thread=2, max_threads=768, lds_budget_bytes=81920)])
+@pytest.mark.parametrize("kw", [dict(), dict(balance_slots=False), dict(lds_budget_bytes=40960, max_threads=512),
+                                dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840),
+                                dict(slots_per_thread=4, max_threads=512, lds_budget_bytes=81920),
+                                dict(slots_per_thread=2, max_threads=1024, lds_budget_bytes=163840)])
 @pytest.mark.parametrize("sigma,order", [(0.02, 2), (0.3, 4)])
 def test_multi_tile_hires(ext, kw, sigma, order):
     """kuhn_ball(19) spheres need ~16 tiles each: halo slots, staged shared vertices, finish kernel."""

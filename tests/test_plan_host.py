@@ -33,7 +33,8 @@ def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
 
 
 @pytest.mark.parametrize("kind,S,kw", [
-    ("kuhn8", 3, {}),                                  # one tile per sphere, no halo
+    ("kuhn8", 3, {}),                                  # default: two workgroups per CU, 2 tets per lane
+    ("kuhn8", 3, dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840)),   # one tile per sphere, no halo
     ("kuhn8", 2, dict(lds_budget_bytes=40000)),        # forced multi-tile
     ("kuhn3", 40, {}),                                 # many tiny spheres packed into shared tiles
     ("kuhn12", 1, {}),                                 # ~10k tets: bisected
@@ -51,8 +52,9 @@ def test_plan_replays_to_oracle(ext, kind, S, kw):
     assert info["n_components"] == S
     assert info["total_slots"] >= sc.n_tets
     assert info["block_threads"] % 64 == 0 and 64 <= info["block_threads"] <= 1024
-    assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 163840)
-    assert 4 * info["block_threads"] >= info["max_slots"]
+    assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 81920)
+    assert info["slots_per_thread"] == kw.get("slots_per_thread", 2)
+    assert info["slots_per_thread"] * info["block_threads"] >= info["max_slots"]
 
 
 def test_real_mesh_plan(ext, aveg):

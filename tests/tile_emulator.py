@@ -90,6 +90,7 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
     info = ts.plan_info()
     stage = np.full((max(info["shared_vertex_copies"], 1), 3), np.nan)
     Es = Eb = 0.0
+    vid, off, sdst = finish_lists(ts)
     for T in plan_tiles(ts):
         sp, pl = T["s_pad"], T["planes"]
         ZS = sp
@@ -155,10 +156,11 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         ne = T["n_excl"]
         assert np.all(np.isnan(grad[T["gvid"][:ne]])), "an exclusive vertex was written twice"
         grad[T["gvid"][:ne]] = gs[:ne] * grad_output
-        stage[T["stage_off"]:T["stage_off"] + T["n_verts"] - ne] = gs[ne:]
-    vid, off, idx = finish_lists(ts)
+        rows = sdst[T["stage_off"]:T["stage_off"] + T["n_verts"] - ne]
+        assert np.all(np.isnan(stage[rows])), "two tile copies write the same staging row"
+        stage[rows] = gs[ne:]
     for k in range(len(vid)):
-        rows = stage[idx[off[k]:off[k + 1]]]
+        rows = stage[off[k]:off[k + 1]]
         assert np.all(np.isnan(grad[vid[k]])), "a finish vertex was also written as exclusive"
         grad[vid[k]] = rows.sum(axis=0) * grad_output
     assert not np.isnan(grad).any(), "some vertex received no gradient"

@@ -166,7 +166,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.balance = opt.balance_slots;
     po.num_threads = opt.num_threads;
     po.shuffle = opt.debug_shuffle;
-    if (opt.slots_per_thread) po.slots_per_thread = opt.slots_per_thread;
+    if (opt.slots_per_thread == 2 || opt.slots_per_thread == 4) po.slots_per_thread = opt.slots_per_thread;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;

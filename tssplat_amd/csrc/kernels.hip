@@ -126,6 +126,7 @@ struct KernelArgs {
     const TileDesc *tiles;
     const uint8_t *blob;
     const int32_t *gvid;
+    const int32_t *sdst;  // staging row of every shared tile-vertex copy
     const float *x;
     const float *grad_out;
     float *grad;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 for (; c < c1; ++c) gather4(inc[c]);
             }
             float *dst = v < td.n_excl ? a.grad + size_t(a.gvid[td.vert_off + v]) * 3
-                                       : a.stage + (size_t(td.stage_off) + size_t(v - td.n_excl)) * 3;
+                                       : a.stage + size_t(a.sdst[td.stage_off + (v - td.n_excl)]) * 3;
             const float sc = v < td.n_excl ? gscale : 1.f;
             if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
@@ -487,8 +488,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
     const int64_t stride = int64_t(gridDim.x - 1) * 256;
     for (int64_t k = int64_t(blockIdx.x) * 256 + tid; k < a.n_finish; k += stride) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        for (int32_t e = a.fin_off[k]; e < a.fin_off[k + 1]; ++e) {
-            const float *r = a.stage + size_t(a.fin_idx[e]) * 3;
+        for (int32_t e = a.fin_off[k]; e < a.fin_off[k + 1]; ++e) {  // consecutive rows, tile order
+            const float *r = a.stage + size_t(e) * 3;
             gx += r[0];
             gy += r[1];
             gz += r[2];
@@ -588,6 +589,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.tiles = e.tiles;
         k.blob = e.blob;
         k.gvid = e.gvid;
+        k.sdst = e.fin_idx;
         k.x = e.x;
         k.grad_out = e.grad_out;
         k.grad = e.grad;

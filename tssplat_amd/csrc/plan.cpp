@@ -304,11 +304,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
     nthreads = std::max(1, std::min(nthreads, 64));
-    int max_threads = opt.max_threads > 0 ? opt.max_threads : 1024;
+    int max_threads = opt.max_threads > 0 ? opt.max_threads : 768;
     max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
     Limits lim;
-    lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 160 * 1024;
-    const int spt = opt.slots_per_thread == 2 ? 2 : 4;
+    lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 80 * 1024;
+    const int spt = opt.slots_per_thread == 4 ? 4 : 2;
     lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 8188);  // slot ids are 13-bit fields
     if (lim.budget < tile_lds_bytes(8, 8)) {
         err = "lds_budget_bytes too small";
@@ -703,7 +703,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             for (int32_t i = d.n_excl; i < d.n_verts; ++i) {
                 int32_t v = P.gvid[size_t(d.vert_off) + size_t(i)];
                 int32_t k = fin_of[size_t(v)];
-                P.fin_idx[size_t(cur[size_t(k)]++)] = int32_t(d.stage_off + (i - d.n_excl));
+                // vertex-major staging: the copies of one vertex occupy consecutive rows, in tile order
+                P.fin_idx[size_t(d.stage_off + (i - d.n_excl))] = cur[size_t(k)]++;
             }
         }
     }

@@ -15,13 +15,16 @@
 namespace tsamd {
 
 struct PlanOptions {
-    int lds_budget = 160 * 1024;  // bytes of LDS one workgroup may use
-    int max_threads = 1024;       // workgroup size cap (multiple of 64)
+    // Defaults = the measured optimum on MI355X (profiles/README.md): two 768-thread workgroups per
+    // CU, 2 tets per lane, 80 KiB of LDS each -- 24 waves per CU hide the LDS-gather latency that one
+    // 1024-thread / 160 KiB workgroup (4 tets per lane) leaves exposed.
+    int lds_budget = 80 * 1024;   // bytes of LDS one workgroup may use
+    int max_threads = 768;        // workgroup size cap (multiple of 64)
     int target_owned = 0;         // 0 = auto
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
     int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
-    int slots_per_thread = 4;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
+    int slots_per_thread = 2;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
@@ -80,6 +83,8 @@ struct Plan {
     std::vector<int32_t> gvid;       // all tiles' local->global vertex ids
     std::vector<int32_t> slot_tet;   // per tile s_pad entries, global tet id or -1 (host only)
     std::vector<int64_t> slot_base;  // per tile offset into slot_tet
+    // finish vertex k (global id fin_vid[k]) = sum of staging rows [fin_off[k], fin_off[k+1]);
+    // fin_idx[tile.stage_off + j] = staging row the tile's j-th shared vertex writes to
     std::vector<int32_t> fin_vid, fin_off, fin_idx;
     int64_t n_stage = 0;             // rows in the staging buffer
     int64_t total_slots = 0, total_tile_verts = 0;
