@@ -99,12 +99,27 @@ __device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx
     return m;
 }
 
+// Own-slot variant: consecutive lanes walk consecutive records, where 16-byte accesses are
+// conflict-free but a 4-byte access at +32 is not (48 B stride folds 32 lanes onto 8 banks), so the
+// ninth float travels as a full quad too.
+__device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t idx)
+{
+    const unsigned char *s = lds + idx * 48u;
+    const v4f a = *reinterpret_cast<const v4f *>(s), b = *reinterpret_cast<const v4f *>(s + 16);
+    const v4u c = *reinterpret_cast<const v4u *>(s + 32);
+    asm volatile("" : : "v"(c));
+    Mat9 m;
+    m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
+    m.p8 = __uint_as_float(c.x);
+    return m;
+}
+
 __device__ __forceinline__ void store_slot(unsigned char *lds, uint32_t idx, const float *m)
 {
     unsigned char *s = lds + idx * 48u;
     *reinterpret_cast<v4f *>(s) = v4f{m[0], m[1], m[2], m[3]};
     *reinterpret_cast<v4f *>(s + 16) = v4f{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<float *>(s + 32) = m[8];
+    *reinterpret_cast<v4f *>(s + 32) = v4f{m[8], 0.f, 0.f, 0.f};
 }
 
 // acc = deg * own - sum of the four neighbours (zero slot for a missing one)
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
                 const uint32_t so = uint32_t(p * nq + tid);
                 if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = so;
-                const Mat9 h = laplace_gather(smem, load_slot(smem, so), float(n01 >> kDegShift), nb);
+                const Mat9 h = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
                 sq = __builtin_elementwise_fma(h.p45, h.p45, sq);
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 const uint32_t so = uint32_t(p * nq + tid);
                 if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = so;
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
-                Mat9 q = laplace_gather(smem, load_slot(smem, so), float(n01 >> kDegShift), nb);
+                Mat9 q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
                 q.p01 *= a.c1; q.p23 *= a.c1; q.p45 *= a.c1; q.p67 *= a.c1;
                 q.p8 *= a.c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
