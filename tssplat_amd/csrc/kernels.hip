@@ -652,7 +652,8 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     f.energy = e.energy;
     f.terms = e.terms;
     if (f.n_finish == 0 && !f.energy) return hipSuccess;
-    const int vb = f.n_finish > 0 ? grid_for(f.n_finish, 256, 2048) : 0;
+    // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
+    const int vb = f.n_finish > 0 ? grid_for(f.n_finish, 256, 1 << 20) : 0;
     hipLaunchKernelGGL(finish_kernel, dim3(unsigned(vb + 1)), dim3(256), 0, stream, f);
     return hipGetLastError();
 }

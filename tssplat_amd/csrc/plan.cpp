@@ -214,6 +214,8 @@ struct Splitter {
     std::vector<std::vector<int32_t>> &out;
     std::string &err;
     int rc = OK;
+    bool strict = false;  // strict: a leaf that does not fit aborts the attempt (caller retries with more parts)
+    bool failed = false;
 
     void bbox(const int32_t *ids, int64_t cnt, float lo[3], float hi[3]) const
     {
@@ -252,12 +254,16 @@ struct Splitter {
 
     void split(int32_t *ids, int64_t cnt, int64_t k)
     {
-        if (rc) return;
+        if (rc || failed) return;
         if (k <= 1) {
             int64_t ns, nv;
             measure(M, ids, cnt, S, ns, nv);
             if (lim.fits(ns, nv)) {
                 emit(ids, cnt);
+                return;
+            }
+            if (strict) {
+                failed = true;
                 return;
             }
             if (cnt <= 1) {
@@ -436,7 +442,24 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             }
             std::string local_err;
             Splitter sp{M, lim, cen, S, group_tiles[size_t(g)], local_err};
-            sp.split(ids, cnt, (cnt + target - 1) / target);
+            // Fewest parts whose tiles all fit: start optimistic (owned ~ 0.85 of the slot capacity) and add
+            // parts until no leaf overflows -- splitting an overflowing leaf in two would leave half-empty tiles.
+            bool done = false;
+            if (opt.target_owned <= 0) {
+                int64_t k = std::max<int64_t>(2, (cnt + int64_t(0.85 * double(s_cap)) - 1) / int64_t(0.85 * double(s_cap)));
+                for (int attempt = 0; attempt < 24 && !done; ++attempt) {
+                    group_tiles[size_t(g)].clear();
+                    sp.strict = true;
+                    sp.failed = false;
+                    sp.split(ids, cnt, k);
+                    done = !sp.failed && !sp.rc;
+                    k = std::max<int64_t>(k + 1, (k * 103 + 99) / 100);
+                }
+                if (!done) group_tiles[size_t(g)].clear();
+            }
+            sp.strict = false;
+            sp.failed = false;
+            if (!done) sp.split(ids, cnt, (cnt + target - 1) / target);
             if (sp.rc) {
                 first_rc.store(sp.rc);
                 bool expected = false;
