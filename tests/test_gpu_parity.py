@@ -255,3 +255,24 @@ def test_config3_one_million_tets_properties(ext):
     eb, gb = _eval_gpu(ext, tb, x[half_v:], c1, c2, 2)
     assert abs((ea + eb) - e) <= 1e-5 * abs(e)
     assert np.linalg.norm(np.concatenate([ga, gb]) - g) <= 1e-5 * np.linalg.norm(g)
+
+
+def test_degenerate_inputs(ext):
+    """Empty batches and vertices no tet references: energy 0, gradient 0 (never uninitialised)."""
+    from tssplat_amd import scenes
+    empty = ext.TetSpheres(np.zeros(0, np.float32), np.zeros(0, np.int32))
+    assert empty.n == 0 and empty.nele == 0
+    e = ext.forward(torch.zeros(0, 3, device="cuda"), empty, 1.0, 1.0, 2)
+    assert float(e) == 0.0
+    v, t = scenes.kuhn_ball(2)
+    rest = np.concatenate([v, [[5.0, 5.0, 5.0], [6.0, 6.0, 6.0]]]).astype(np.float32)
+    ts = ext.TetSpheres(rest.reshape(-1), t.reshape(-1))
+    x = torch.from_numpy(rest + 0.05).cuda().requires_grad_(True)
+    x.data[:27] += 0.1 * torch.randn(27, 3, device="cuda")
+    e = ext.forward(x, ts, 1.0, 1.0, 2)
+    g = ext.backward(torch.tensor(1.0), x, ts, 1.0, 1.0, 2)
+    assert torch.isfinite(e) and torch.isfinite(g).all()
+    assert torch.all(g[-2:] == 0)
+    # poisoned output buffers must be fully overwritten by the non-cached backward as well
+    g2 = ext.backward(torch.tensor(1.0), x.detach(), ts, 1.0, 1.0, 2)
+    assert torch.allclose(g, g2, rtol=1e-6, atol=1e-7)

@@ -72,7 +72,6 @@ class TetSpheres:
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
         self._cache = None
-        self._ws = None
         self.fuse_forward_backward = True
         self.device = None
         if vertices is None and elements is None:
