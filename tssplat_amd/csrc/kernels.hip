@@ -184,6 +184,11 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
 {
     typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
     typedef float VF __attribute__((ext_vector_type(SPT)));
+#ifdef TSAMD_FORCE_RELOAD
+    constexpr bool kReload = true;
+#else
+    constexpr bool kReload = SPT > 2;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
@@ -312,13 +317,15 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
         int pc0 = 0, pc1 = 0;
         uint2 pre[kPre];
         if (active) {
-            // Dm^-1 and the vertex ids are needed again by pass 3.  Re-issuing their 11 loads here
-            // instead of pinning 44 VGPRs across pass 2 keeps the kernel inside 128 VGPRs
-            // (16 waves/CU) without scratch spills.
-            q_lv01 = plane_u(0);
-            q_lv23 = plane_u(1);
+            // Dm^-1 is needed again by pass 3.  With 4 slots per lane, pinning its 36 VGPRs (+8 of vertex
+            // offsets) across pass 2 spills, so those builds re-issue the 11 plane loads here (L2 hit rate
+            // 44 %: the measured 1.5x HBM over-fetch).  With 2 slots per lane it stays in registers.
+            if (kReload) {
+                q_lv01 = plane_u(0);
+                q_lv23 = plane_u(1);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+                for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+            }
 #pragma unroll
             for (int p = 0; p < SPT; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
         }
@@ -342,6 +349,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 q.p8 *= a.c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
+                    if (!kReload) {  // rare path: fetch the vertex offsets again instead of pinning them
+                        q_lv01 = plane_u(0);
+                        q_lv23 = plane_u(1);
+                    }
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
                     slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
@@ -468,40 +479,56 @@ struct FinishArgs {
     double *terms;
 };
 
-// Vertices touched by several tiles: sum their staged partial gradients in plan order
-// (deterministic).  The last workgroup folds the per-tile energy partials, again in fixed order.
+// Per-tile energy partials -> E = c1 E_s + c2 E_b (tet_spheres_cuda.cu:191), one workgroup, fixed order
+// (bitwise repeatable).  Each thread owns tiles tid, tid + 1024, ... and issues its loads in batches of
+// eight before summing: a plain dependent loop costs one HBM latency per tile (60 us for 19 k tiles).
+__global__ __launch_bounds__(1024) void energy_reduce_kernel(const FinishArgs a)
+{
+    __shared__ double red[2 * 1024];
+    const int tid = threadIdx.x;
+    const double2 *part = reinterpret_cast<const double2 *>(a.partials);
+    double s = 0.0, b = 0.0;
+    int64_t t = tid;
+    for (; t + 7 * 1024 < a.n_tiles; t += 8 * 1024) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[t + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s += v[u].x;
+            b += v[u].y;
+        }
+    }
+    for (; t < a.n_tiles; t += 1024) {
+        const double2 v = part[t];
+        s += v.x;
+        b += v.y;
+    }
+    red[tid] = s;
+    red[1024 + tid] = b;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) {
+            red[tid] += red[tid + off];
+            red[1024 + tid] += red[1024 + tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        a.terms[0] = red[0];
+        a.terms[1] = red[1024];
+        a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[1024]);
+    }
+}
+
+// Vertices touched by several tiles: sum their staged partial gradients in plan order (deterministic).
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
 {
-    __shared__ double red[2 * 256];
     const int tid = threadIdx.x;
-    if (blockIdx.x == gridDim.x - 1) {
-        if (!a.energy) return;
-        double s = 0.0, b = 0.0;
-        for (int64_t t = tid; t < a.n_tiles; t += 256) {
-            s += a.partials[2 * t];
-            b += a.partials[2 * t + 1];
-        }
-        red[tid] = s;
-        red[256 + tid] = b;
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) {
-                red[tid] += red[tid + off];
-                red[256 + tid] += red[256 + tid + off];
-            }
-            __syncthreads();
-        }
-        if (tid == 0) {
-            a.terms[0] = red[0];
-            a.terms[1] = red[256];
-            a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[256]);
-        }
-        return;
-    }
     if (!a.grad) return;
     const float gscale = a.grad_out ? *a.grad_out : 1.f;
     // one thread per shared vertex (measured faster than one thread per output float: 0.065 vs 0.093 ms)
-    const int64_t stride = int64_t(gridDim.x - 1) * 256;
+    const int64_t stride = int64_t(gridDim.x) * 256;
     for (int64_t k = int64_t(blockIdx.x) * 256 + tid; k < a.n_finish; k += stride) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
         for (int32_t e = a.fin_off[k]; e < a.fin_off[k + 1]; ++e) {  // consecutive rows, tile order
@@ -520,6 +547,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
 __global__ __launch_bounds__(256) void scale_kernel(const float *in, const float *scalar, float *out, int64_t n)
 {
     const float s = *scalar;
+    if (in == out && s == 1.f) return;  // in-place by exactly 1 (the usual autograd grad_output): nothing to do
     const int64_t stride = int64_t(gridDim.x) * 256;
     const int64_t n4 = n >> 2;
     const float4 *in4 = reinterpret_cast<const float4 *>(in);
@@ -652,11 +680,17 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     f.c2 = e.c2;
     f.energy = e.energy;
     f.terms = e.terms;
-    if (f.n_finish == 0 && !f.energy) return hipSuccess;
-    // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
-    const int vb = f.n_finish > 0 ? grid_for(f.n_finish, 256, 1 << 20) : 0;
-    hipLaunchKernelGGL(finish_kernel, dim3(unsigned(vb + 1)), dim3(256), 0, stream, f);
-    return hipGetLastError();
+    if (f.energy) {
+        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+    }
+    if (f.n_finish > 0) {
+        // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
+        hipLaunchKernelGGL(finish_kernel, dim3(unsigned(grid_for(f.n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
+        return hipGetLastError();
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream)

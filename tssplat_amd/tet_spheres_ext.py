@@ -196,14 +196,18 @@ def backward(gradH: torch.Tensor, input: torch.Tensor, tet_sph: TetSpheres, c1: 
     if not isinstance(gradH, torch.Tensor):
         gradH = torch.tensor(float(gradH), dtype=torch.float32)
     go = gradH.detach().to(device=x.device, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
-    out = torch.empty_like(x)
+    out = None
     stream = _stream_ptr(x.device)
     with torch.cuda.device(x.device):
         cached = tet_sph._cache
         tet_sph._cache = None
         if cached is not None and cached[0] == _cache_key(input, c1, c2, order):
-            _capi.check(_lib.tsamd_scale(cached[1].data_ptr(), go.data_ptr(), out.data_ptr(), out.numel(), stream))
+            # the cached gradient is ours: scale it in place (the kernel returns at once when gradH == 1,
+            # the usual case for a loss term, so no second pass over the gradient) and hand it over
+            out = cached[1]
+            _capi.check(_lib.tsamd_scale(out.data_ptr(), go.data_ptr(), out.data_ptr(), out.numel(), stream))
         else:
+            out = torch.empty_like(x)
             _capi.check(_lib.tsamd_backward(h, x.data_ptr(), go.data_ptr(), c1, c2, int(order), stream,
                                             out.data_ptr()))
     return out.view(input.shape)
