@@ -62,7 +62,7 @@ typedef struct tsamd_options {
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
-    int32_t debug_shuffle;     /* experiment: spread a tile's tets over lanes instead of Morton order */
+    int32_t debug_shuffle;     /* experiments: bit0 = spread a tile's tets over lanes, bit1 = no LDS-conflict-aware ordering */
     int32_t slots_per_thread;  /* tets streamed per lane: 2 (8 B loads, default) or 4 (16 B loads)  */
 } tsamd_options;
 

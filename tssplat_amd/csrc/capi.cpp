@@ -165,7 +165,8 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.target_owned = opt.target_owned;
     po.balance = opt.balance_slots;
     po.num_threads = opt.num_threads;
-    po.shuffle = opt.debug_shuffle;
+    po.shuffle = opt.debug_shuffle & 1;
+    po.conflict_aware = (opt.debug_shuffle & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware ordering off
     if (opt.slots_per_thread == 2 || opt.slots_per_thread == 4) po.slots_per_thread = opt.slots_per_thread;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");

@@ -668,6 +668,63 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
                     }
             }
+            // ---- LDS bank-conflict-aware neighbour order ----
+            // A wave reads neighbour k of 16 lanes' tets with one ds_read_b128 per 16-lane group; two lanes
+            // collide when their records share a 16-byte bank column, i.e. when the record indices agree
+            // mod 16 (48 B stride: column = 3 * idx mod 16).  The order of a tet's four neighbours is free,
+            // so within every lane group pick, step by step, neighbours with distinct residues.
+            if (opt.conflict_aware) {
+                static const int kGroups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                                   {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+                                                   {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+                uint32_t *p2 = pl + 2 * size_t(d.s_pad), *p3 = pl + 3 * size_t(d.s_pad);
+                for (int32_t pp = 0; pp < spt; ++pp)
+                    for (int32_t base = 0; base < nq; base += 64)
+                        for (int gi = 0; gi < 4; ++gi) {
+                            int32_t lane_slot[16];
+                            uint32_t cand[16][4];
+                            int nl = 0;
+                            for (int li = 0; li < 16; ++li) {
+                                const int32_t tl = base + kGroups[gi][li];
+                                if (tl >= nq) continue;
+                                const int32_t sl = spt * tl + pp;
+                                lane_slot[nl] = sl;
+                                cand[nl][0] = p2[sl] & kSlotMask;
+                                cand[nl][1] = (p2[sl] >> 16) & kSlotMask;
+                                cand[nl][2] = p3[sl] & 0xffffu;
+                                cand[nl][3] = p3[sl] >> 16;
+                                ++nl;
+                            }
+                            uint32_t chosen[16][4];
+                            bool taken[16][4] = {};
+                            for (int step = 0; step < 4; ++step) {
+                                int64_t colrec[16];
+                                for (auto &c : colrec) c = -1;
+                                for (int li = 0; li < nl; ++li) {
+                                    int pick = -1;
+                                    for (int c = 0; c < 4 && pick < 0; ++c) {
+                                        if (taken[li][c]) continue;
+                                        const uint32_t r = cand[li][c] & 15u;
+                                        if (colrec[r] < 0 || colrec[r] == int64_t(cand[li][c])) pick = c;
+                                    }
+                                    if (pick < 0)
+                                        for (int c = 0; c < 4 && pick < 0; ++c)
+                                            if (!taken[li][c]) pick = c;
+                                    taken[li][pick] = true;
+                                    chosen[li][step] = cand[li][pick];
+                                    const uint32_t r = cand[li][pick] & 15u;
+                                    if (colrec[r] < 0) colrec[r] = int64_t(cand[li][pick]);
+                                }
+                            }
+                            for (int li = 0; li < nl; ++li) {
+                                const int32_t sl = lane_slot[li];
+                                p2[sl] = (p2[sl] & ~(kSlotMask | (kSlotMask << 16))) | chosen[li][0] | (chosen[li][1] << 16);
+                                p3[sl] = chosen[li][2] | (chosen[li][3] << 16);
+                            }
+                        }
+            }
+
             // vertex incidence lists (the gradient is gathered per vertex, in this fixed order)
             {
                 uint16_t *inc = reinterpret_cast<uint16_t *>(pl + size_t(kPlanes) * size_t(d.s_pad));
@@ -692,6 +749,31 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     for (int a = 0; a < 4; ++a) {
                         int32_t v = S.vert_local[tets[4 * int64_t(stet[sl]) + a]];
                         inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq, spt)) << 2) | uint32_t(a));
+                    }
+                }
+                // Conflict-aware order inside every list: lane v reads the 3 floats of its s-th entry at byte
+                // 12 * entry with 4-byte reads (32-lane groups, bank = (3 * entry + c) mod 32), so two lanes
+                // collide when their entries agree mod 32.  List order is free (it only fixes the summation
+                // order): per 32-vertex group and step, hand every vertex an entry with an unused residue.
+                if (opt.conflict_aware) {
+                    for (int32_t vb = 0; vb < d.n_verts; vb += 32) {
+                        const int32_t ve = std::min<int32_t>(vb + 32, d.n_verts);
+                        int32_t maxlen = 0;
+                        for (int32_t v = vb; v < ve; ++v) maxlen = std::max(maxlen, cnt[size_t(v)]);
+                        for (int32_t step = 0; step < maxlen; ++step) {
+                            int32_t colrec[32];
+                            for (auto &c : colrec) c = -1;
+                            for (int32_t v = vb; v < ve; ++v) {
+                                if (step >= cnt[size_t(v)]) continue;
+                                uint16_t *lst = inc + 4 * size_t(inc_off[v]);
+                                int32_t pick = -1;
+                                for (int32_t c = step; c < cnt[size_t(v)] && pick < 0; ++c)
+                                    if (colrec[lst[c] & 31u] < 0) pick = c;
+                                if (pick < 0) pick = step;
+                                std::swap(lst[step], lst[pick]);
+                                if (colrec[lst[step] & 31u] < 0) colrec[lst[step] & 31u] = lst[step];
+                            }
+                        }
                     }
                 }
             }

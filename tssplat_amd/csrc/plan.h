@@ -25,6 +25,7 @@ struct PlanOptions {
     int num_threads = 0;          // 0 = hardware concurrency
     int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
     int slots_per_thread = 2;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
+    int conflict_aware = 1;       // order neighbour / incidence entries to dodge LDS bank conflicts
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).

@@ -67,7 +67,7 @@ class TetSpheres:
 
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
-                 balance_slots: bool = True, num_threads: int = 0, debug_shuffle: bool = False,
+                 balance_slots: bool = True, num_threads: int = 0, debug_shuffle: int = 0,
                  slots_per_thread: int = 0):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
