@@ -36,6 +36,7 @@ constexpr int kWave = 64;
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float det3(const float *F)
 {
@@ -55,6 +56,16 @@ __device__ __forceinline__ void cof3(const float *F, float *C)
     C[6] = F[1] * F[5] - F[2] * F[4];
     C[7] = F[2] * F[3] - F[0] * F[5];
     C[8] = F[0] * F[4] - F[1] * F[3];
+}
+
+// Explicit global-address-space views of the kernel's pointers.  In the out-of-line tile body the compiler
+// cannot infer the address space of pointers read from KernelArgs and would emit flat_* loads, which share
+// the LDS counter (lgkmcnt): every LDS wait would then also wait for outstanding HBM loads.
+#define GLOBAL_AS __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GLOBAL_AS T *as_global(T *p)
+{
+    return (GLOBAL_AS T *)p;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -151,6 +162,7 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
+    int sa_max, vp_max;  // persistent launches: LDS layout for the largest tile of the plan
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
     long long *clk;  // ablation builds: 16 shader-clock stamps per tile (phase boundaries of thread 0)
 };
@@ -179,9 +191,15 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
 // SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
 // SIMD): <1024, 4> gives 128 VGPRs and one workgroup per CU, <768, 6> 80 VGPRs and two.
-template <bool WITH_GRAD, int BLOCK, int SPT, int WPE>
-__global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
+// Everything one workgroup does for one tile.  `next` >= 0 (persistent walk) names the tile this workgroup
+// takes afterwards: its vertex positions are staged into xs as soon as this tile is done with them, and
+// its planes are touched so that the next call streams them from L2 rather than HBM.
+template <bool WITH_GRAD, int SPT>
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int next, const int SA, const int VP)
 {
+    // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
+    // out-of-line copy would turn into a flat_* instruction
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
     typedef float VF __attribute__((ext_vector_type(SPT)));
 #ifdef TSAMD_FORCE_RELOAD
@@ -189,34 +207,27 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
 #else
     constexpr bool kReload = SPT > 2;
 #endif
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
-    // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2 and the halo
-    // planes two neighbouring tiles both read are served from it.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int tile = xcd * a.tiles_per_xcd + j;
-    if (j >= a.tiles_per_xcd || tile >= a.n_tiles) return;
-
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int nq = td.s_pad / SPT;
-    const int SA = td.s_pad + 4;
-    const int VP = (td.n_verts + 3) & ~3;
-    const uint32_t ZS = uint32_t(td.s_pad);
-
+    const auto g_blob = as_global(a.blob);
+    const auto g_gvid = as_global(a.gvid);
+    const auto g_sdst = as_global(a.sdst);
+    const auto g_x = as_global(a.x);
+    const auto g_grad = as_global(a.grad);
+    const auto g_stage = as_global(a.stage);
+    const auto g_partials = as_global(a.partials);
     unsigned char *xs = smem + 48 * SA;
     double *red = reinterpret_cast<double *>(xs + 16 * VP);
-
+    const int nq = td.s_pad / SPT;
+    const uint32_t ZS = uint32_t(td.s_pad);
     const bool active = tid < nq;
-    const uint32_t *pl = reinterpret_cast<const uint32_t *>(a.blob + td.blob_off);  // 13 planes of s_pad dwords
+    const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);  // 13 planes of s_pad dwords
+    auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * tid); };
+    auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * tid); };
     STAMP(0);
-
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
     VU q_lv01 = 0, q_lv23 = 0, q_nb01 = 0, q_nb23 = 0;
     VF dm[9];
-    auto plane_u = [&](int q) { return *reinterpret_cast<const VU *>(pl + q * td.s_pad + SPT * tid); };
-    auto plane_f = [&](int q) { return *reinterpret_cast<const VF *>(pl + q * td.s_pad + SPT * tid); };
     if (active) {
         q_lv01 = plane_u(0);
         q_lv23 = plane_u(1);
@@ -225,18 +236,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
 #pragma unroll
         for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     }
-    // ---- stage the tile's vertex positions ----
-    for (int v = tid; v < td.n_verts; v += nthr) {
-        const size_t gv = size_t(a.gvid[td.vert_off + v]) * 3;
-        reinterpret_cast<float4 *>(xs)[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
-    }
-    if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot
-    __syncthreads();
-    STAMP(1);  // planes + positions landed
+    if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
+    STAMP(1);
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
         float chk = dm[0][0] + dm[4][1] + dm[8][SPT - 1] + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
                     reinterpret_cast<float *>(xs)[tid % td.n_verts];
-        if (chk == 12345.678f) a.partials[0] = chk;
+        if (chk == 12345.678f) g_partials[0] = chk;
         return;
     }
 
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     __syncthreads();
     STAMP(2);  // pass 1 done
     if (DBG(DBG_EXIT_AFTER_P1)) {
-        if (e_b == 12345.678f) a.partials[0] = e_b;
+        if (e_b == 12345.678f) g_partials[0] = e_b;
         return;
     }
 
@@ -307,15 +312,19 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     __syncthreads();  // every read of F is done; overwrite it with H in place
     STAMP(3);  // pass 2 done
 
+    const bool has_next = next >= 0;
+    TileDesc tdn = td;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    uint32_t warm[kPlanes];
     if (WITH_GRAD) {
         // vertex incidence lists (thread t gathers local vertex t): fetch the first kPre chunks now so
         // that their HBM latency hides behind pass 3
         constexpr int kPre = 6;
-        const uint2 *inc = reinterpret_cast<const uint2 *>(pl + kPlanes * td.s_pad);
-        const uint16_t *inc_off = reinterpret_cast<const uint16_t *>(inc + td.n_inc4);
+        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kPlanes * td.s_pad);
+        const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
         const uint32_t pad16 = (ZS << 2) | 1u;
         int pc0 = 0, pc1 = 0;
-        uint2 pre[kPre];
+        v2u pre[kPre];
         if (active) {
             // Dm^-1 is needed again by pass 3.  With 4 slots per lane, pinning its 36 VGPRs (+8 of vertex
             // offsets) across pass 2 spills, so those builds re-issue the 11 plane loads here (L2 hit rate
@@ -379,11 +388,28 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
             pc1 = inc_off[tid + 1];
 #pragma unroll
             for (int q = 0; q < kPre; ++q)
-                pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : make_uint2(pad16 * 0x10001u, pad16 * 0x10001u);
+                pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
+        }
+        // ---- persistent walk: start fetching the next tile's vertex positions (4 registers) ----
+        if (has_next) {
+            tdn = a.tiles[next];
+            if (tid < tdn.n_verts) {
+                const size_t gv = size_t(g_gvid[tdn.vert_off + tid]) * 3;
+                nx = g_x[gv];
+                ny = g_x[gv + 1];
+                nz = g_x[gv + 2];
+            }
         }
         STAMP(5);  // pass 3 compute done (this wave)
         __syncthreads();
-        STAMP(6);  // all waves done with H
+        STAMP(6);  // all waves done with H and with the staged positions
+        if (has_next) {  // xs is free now: stage the next tile's positions
+            if (tid < tdn.n_verts) reinterpret_cast<float4 *>(xs)[tid] = make_float4(nx, ny, nz, 0.f);
+            for (int v = tid + nthr; v < tdn.n_verts; v += nthr) {
+                const size_t gv = size_t(g_gvid[tdn.vert_off + v]) * 3;
+                reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+            }
+        }
         // ---- write the vertex forces: record = (f0.xyz, f1.xyz, f2.xyz, f3.xyz), f0 = -(f1 + f2 + f3) ----
         if (active) {
 #pragma unroll
@@ -395,6 +421,13 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 *reinterpret_cast<v4f *>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
             }
         }
+        if (has_next) {  // touch the next tile's planes so that its stream phase hits L2 instead of HBM
+            const GLOBAL_AS uint32_t *pln = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + tdn.blob_off);
+            if (tid < tdn.s_pad / SPT) {
+#pragma unroll
+                for (int q = 0; q < kPlanes; ++q) warm[q] = pln[q * tdn.s_pad + SPT * tid];
+            }
+        }
         __syncthreads();
         STAMP(7);  // vertex forces written
 
@@ -402,10 +435,10 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
         // Entry e = (lds slot << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
         // point into the all-zero slot.  Exclusive vertices go straight to grad, vertices shared with
         // other tiles to the staging rows, which the finish kernel sums in plan order.
-        const float gscale = a.grad_out ? *a.grad_out : 1.f;
+        const float gscale = a.grad_out ? *as_global(a.grad_out) : 1.f;
         for (int v = tid; v < td.n_verts; v += nthr) {
             float gx = 0.f, gy = 0.f, gz = 0.f;
-            auto gather4 = [&](const uint2 w) {
+            auto gather4 = [&](const v2u w) {
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -428,8 +461,8 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
                 }
                 for (; c < c1; ++c) gather4(inc[c]);
             }
-            float *dst = v < td.n_excl ? a.grad + size_t(a.gvid[td.vert_off + v]) * 3
-                                       : a.stage + size_t(a.sdst[td.stage_off + (v - td.n_excl)]) * 3;
+            GLOBAL_AS float *dst = v < td.n_excl ? g_grad + size_t(g_gvid[td.vert_off + v]) * 3
+                                                 : g_stage + size_t(g_sdst[td.stage_off + (v - td.n_excl)]) * 3;
             const float sc = v < td.n_excl ? gscale : 1.f;
             if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
@@ -460,10 +493,54 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
             s += red[2 * w];
             b += red[2 * w + 1];
         }
-        a.partials[2 * size_t(tile)] = s;
-        a.partials[2 * size_t(tile) + 1] = b;
+        g_partials[2 * size_t(tile)] = s;
+        g_partials[2 * size_t(tile) + 1] = b;
     }
     STAMP(9);
+    if (has_next && tid < tdn.s_pad / SPT) {  // retire the warm-up loads
+#pragma unroll
+        for (int q = 0; q < kPlanes; ++q) asm volatile("" : : "v"(warm[q]));
+    }
+}
+
+// PERSIST: the workgroup walks a strided sequence of tiles and hides the next tile's stream phase behind the
+// current tile's tail (positions prefetched into LDS, planes touched into L2).  No per-lane state is carried
+// from one tile to the next, which keeps the register allocation of the loop body at the one-tile level.
+template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool PERSIST>
+__global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
+{
+    static_assert(!PERSIST || WITH_GRAD, "the persistent walk is only built for the fused kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
+    // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2 and the halo
+    // planes two neighbouring tiles both read are served from it.
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_step = PERSIST ? int(gridDim.x >> 3) : a.tiles_per_xcd;
+    const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
+    int tile = xcd * a.tiles_per_xcd + jb;
+    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
+
+    const TileDesc td0 = a.tiles[tile];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int SA = PERSIST ? a.sa_max : td0.s_pad + 4;
+    const int VP = PERSIST ? a.vp_max : (td0.n_verts + 3) & ~3;
+    // ---- stage the (first) tile's vertex positions ----
+    for (int v = tid; v < td0.n_verts; v += nthr) {
+        const size_t gv = size_t(a.gvid[td0.vert_off + v]) * 3;
+        reinterpret_cast<float4 *>(smem + 48 * SA)[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
+    }
+    __syncthreads();
+    if (!PERSIST) {
+        tile_body<WITH_GRAD, SPT>(a, tile, -1, SA, VP);
+    } else {
+        for (;;) {
+            const int next = tile + tile_step < tile_end ? tile + tile_step : -1;
+            tile_body<WITH_GRAD, SPT>(a, tile, next, SA, VP);  // inlined: no per-lane state is carried between tiles
+            if (next < 0) break;
+            tile = next;
+        }
+    }
 }
 
 struct FinishArgs {
@@ -602,12 +679,13 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
 
 hipError_t configure_kernels(int lds_bytes)
 {
-    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>)};
+    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6, false>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, true>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -646,17 +724,27 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.dbg = e.dbg;
         k.clk = e.clk;
-        const dim3 grid(unsigned(8 * k.tiles_per_xcd)), block(unsigned(e.block_threads));
+        const dim3 block(unsigned(e.block_threads));
         // 2 slots per lane and two workgroups per CU (<= 80 KiB LDS, <= 768 threads): the 80-VGPR build
         const bool two_per_cu = e.spt == 2 && e.block_threads <= 768 && e.lds_bytes <= 80 * 1024;
-#define TSAMD_LAUNCH(G, B, S, W) \
-    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(e.lds_bytes), stream, k)
-        if (e.spt == 2 && two_per_cu) {
-            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
+        const bool persist = e.grad && two_per_cu && e.persistent_blocks > 0 && e.lds_bytes_persistent <= 80 * 1024 &&
+                             e.n_tiles > e.persistent_blocks;
+        k.sa_max = e.sa_max;
+        k.vp_max = e.vp_max;
+#define TSAMD_LAUNCH(G, B, S, W, P) \
+    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W, P>), grid, block, size_t(lds), stream, k)
+        size_t lds = size_t(e.lds_bytes);
+        dim3 grid(unsigned(8 * k.tiles_per_xcd));
+        if (persist) {
+            lds = size_t(e.lds_bytes_persistent);
+            grid = dim3(unsigned((e.persistent_blocks + 7) / 8 * 8));
+            TSAMD_LAUNCH(true, 768, 2, 6, true);
+        } else if (e.spt == 2 && two_per_cu) {
+            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6, false); else TSAMD_LAUNCH(false, 768, 2, 6, false);
         } else if (e.spt == 2) {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4); else TSAMD_LAUNCH(false, 1024, 2, 4);
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4, false); else TSAMD_LAUNCH(false, 1024, 2, 4, false);
         } else {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4); else TSAMD_LAUNCH(false, 1024, 4, 4);
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4, false); else TSAMD_LAUNCH(false, 1024, 4, 4, false);
         }
 #undef TSAMD_LAUNCH
         hipError_t err = hipGetLastError();
