@@ -195,7 +195,8 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // takes afterwards: its vertex positions are staged into xs as soon as this tile is done with them, and
 // its planes are touched so that the next call streams them from L2 rather than HBM.
 template <bool WITH_GRAD, int SPT>
-__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int next, const int SA, const int VP)
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int next, const int SA, const int VP,
+                                          const bool stage_self)
 {
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
     // out-of-line copy would turn into a flat_* instruction
@@ -237,6 +238,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     }
     if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
+    if (stage_self) {  // stage this tile's vertex positions (behind the plane loads just issued)
+        for (int v = tid; v < td.n_verts; v += nthr) {
+            const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
+            reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+        }
+        __syncthreads();
+    }
     STAMP(1);
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
         float chk = dm[0][0] + dm[4][1] + dm[8][SPT - 1] + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
@@ -522,21 +530,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
 
     const TileDesc td0 = a.tiles[tile];
-    const int tid = threadIdx.x, nthr = blockDim.x;
     const int SA = PERSIST ? a.sa_max : td0.s_pad + 4;
     const int VP = PERSIST ? a.vp_max : (td0.n_verts + 3) & ~3;
-    // ---- stage the (first) tile's vertex positions ----
-    for (int v = tid; v < td0.n_verts; v += nthr) {
-        const size_t gv = size_t(a.gvid[td0.vert_off + v]) * 3;
-        reinterpret_cast<float4 *>(smem + 48 * SA)[v] = make_float4(a.x[gv], a.x[gv + 1], a.x[gv + 2], 0.f);
-    }
-    __syncthreads();
     if (!PERSIST) {
-        tile_body<WITH_GRAD, SPT>(a, tile, -1, SA, VP);
+        tile_body<WITH_GRAD, SPT>(a, tile, -1, SA, VP, true);
     } else {
-        for (;;) {
+        for (bool first = true;; first = false) {
             const int next = tile + tile_step < tile_end ? tile + tile_step : -1;
-            tile_body<WITH_GRAD, SPT>(a, tile, next, SA, VP);  // inlined: no per-lane state is carried between tiles
+            tile_body<WITH_GRAD, SPT>(a, tile, next, SA, VP, first);  // inlined: no per-lane state is carried between tiles
             if (next < 0) break;
             tile = next;
         }

@@ -56,6 +56,12 @@ def _stream_ptr(device: torch.device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _device_ctx(device: torch.device):
+    """Handle-less entry points (scale, grad_limit) launch on the current device: switch only if needed."""
+    import contextlib
+    return contextlib.nullcontext() if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 class TetSpheres:
     """Device state for one batch of tet-spheres (reference: tet_spheres.h:9-42).
 
@@ -175,14 +181,14 @@ def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, orde
     x = _check_input(input, tet_sph)
     energy = torch.empty((), dtype=torch.float32, device=x.device)
     stream = _stream_ptr(x.device)
-    with torch.cuda.device(x.device):
-        if input.requires_grad and tet_sph.fuse_forward_backward:
-            g = torch.empty_like(x)
-            _capi.check(_lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, int(order), stream,
-                                                    energy.data_ptr(), g.data_ptr()))
-            tet_sph._cache = (_cache_key(input, c1, c2, order), g)
-        else:
-            _capi.check(_lib.tsamd_forward(h, x.data_ptr(), c1, c2, int(order), stream, energy.data_ptr()))
+    # (no torch.cuda.device() guard: the library switches to the handle's device itself)
+    if input.requires_grad and tet_sph.fuse_forward_backward:
+        g = torch.empty_like(x)
+        _capi.check(_lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, int(order), stream,
+                                                energy.data_ptr(), g.data_ptr()))
+        tet_sph._cache = (_cache_key(input, c1, c2, order), g)
+    else:
+        _capi.check(_lib.tsamd_forward(h, x.data_ptr(), c1, c2, int(order), stream, energy.data_ptr()))
     if os.environ.get("TSSPLAT_AMD_CPU_ENERGY", "0") == "1":
         return energy.cpu()                             # the reference's convention, .cu:194
     return energy
@@ -196,20 +202,19 @@ def backward(gradH: torch.Tensor, input: torch.Tensor, tet_sph: TetSpheres, c1: 
     if not isinstance(gradH, torch.Tensor):
         gradH = torch.tensor(float(gradH), dtype=torch.float32)
     go = gradH.detach().to(device=x.device, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
-    out = None
     stream = _stream_ptr(x.device)
-    with torch.cuda.device(x.device):
-        cached = tet_sph._cache
-        tet_sph._cache = None
-        if cached is not None and cached[0] == _cache_key(input, c1, c2, order):
-            # the cached gradient is ours: scale it in place (the kernel returns at once when gradH == 1,
-            # the usual case for a loss term, so no second pass over the gradient) and hand it over
-            out = cached[1]
+    cached = tet_sph._cache
+    tet_sph._cache = None
+    if cached is not None and cached[0] == _cache_key(input, c1, c2, order):
+        # the cached gradient is ours: scale it in place (the kernel returns at once when gradH == 1,
+        # the usual case for a loss term, so no second pass over the gradient) and hand it over
+        out = cached[1]
+        with _device_ctx(x.device):
             _capi.check(_lib.tsamd_scale(out.data_ptr(), go.data_ptr(), out.data_ptr(), out.numel(), stream))
-        else:
-            out = torch.empty_like(x)
-            _capi.check(_lib.tsamd_backward(h, x.data_ptr(), go.data_ptr(), c1, c2, int(order), stream,
-                                            out.data_ptr()))
+    else:
+        out = torch.empty_like(x)
+        _capi.check(_lib.tsamd_backward(h, x.data_ptr(), go.data_ptr(), c1, c2, int(order), stream,
+                                        out.data_ptr()))
     return out.view(input.shape)
 
 
@@ -223,6 +228,6 @@ def grad_limit(grad: torch.Tensor, s_threshold: float, s: float) -> None:
     if not grad.is_cuda or grad.dtype != torch.float32 or not grad.is_contiguous():
         raise RuntimeError("grad_limit expects a contiguous float32 GPU tensor")
     ws = torch.empty(int(_lib.tsamd_grad_limit_workspace_bytes()), dtype=torch.uint8, device=grad.device)
-    with torch.cuda.device(grad.device):
+    with _device_ctx(grad.device):
         _capi.check(_lib.tsamd_grad_limit(grad.data_ptr(), grad.numel(), float(s_threshold), float(s),
                                           ws.data_ptr(), _stream_ptr(grad.device)))
