@@ -167,6 +167,20 @@ int64_t tsamd_grad_limit_workspace_bytes(void);
 int tsamd_grad_limit(float *grad_dev, int64_t n, float s_threshold, float s, void *workspace_dev,
                      void *stream);
 
+/*
+ * SURVEY 8(f) row 3 -- the optimiser step that follows every backward: one fused AdamUniform step
+ * (reference utils/optimizer.py:38-89) over a contiguous float32 parameter, in place, no host sync
+ * (the reference takes two .max() reductions and, with grad_limit, a Python `if s > m` per step).
+ *   g1 = b1 g1 + (1-b1) grad;  g2 = b2 g2 + (1-b2) grad^2;            optimizer.py:61-62
+ *   gr = (g1 / (1-b1^step)) / (1e-8 + max sqrt(g2 / (1-b2^step)));    optimizer.py:67-74
+ *   if grad_limit > 0 and max|gr| > grad_limit: gr *= grad_limit / max|gr|;   optimizer.py:84-86
+ *   param -= lr * gr                                                   optimizer.py:88
+ * `step` is the 1-based count AFTER the increment of optimizer.py:55.  workspace_dev: >= 16 bytes.
+ */
+int tsamd_adam_uniform_step(float *param_dev, const float *grad_dev, float *g1_dev, float *g2_dev, int64_t n,
+                            float lr, float beta1, float beta2, int64_t step, float grad_limit,
+                            void *workspace_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,8 @@ exists on the GPU box, hence the outputs are committed:
   function on (a) 192 tets of a.veg (with the vertices they touch, float32
   positions promoted to float64 exactly as tet_spheres.cpp:252-255 does) and
   (b) a full kuhn_ball(2).  Pins the oracle's `G` (oracle/tet_energy_oracle.py).
+* adam_uniform_golden.npz -- six steps of the REFERENCE optimiser class (utils/optimizer.py:4-89) in
+  float64, with and without grad_limit: pins oracle/adam_uniform_oracle.py.
 * aveg_mesh.npz -- a.veg converted to the extension's input layout
   (float32 [n,3], int32 [m,4], 0-based): the "real TetWild-quality mesh"
   fixture of SURVEY.md 8(d).
@@ -55,6 +57,32 @@ def main():
         aveg_rest=sub_v, aveg_tets=sub_t, aveg_tet_ids=pick.astype(np.int32), aveg_G=G_a,
         kuhn2_rest=kv32, kuhn2_tets=kt.astype(np.int32), kuhn2_G=G_k,
     )
+    # ---- AdamUniform golden trajectory from the reference class itself (utils/optimizer.py:4-89) ----
+    import torch
+    spec = importlib.util.spec_from_file_location("ref_optimizer", f"{REF}/utils/optimizer.py")
+    ro = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ro)
+    out = {}
+    for name, kw in (("plain", dict(lr=0.2)), ("limited", dict(lr=0.2, grad_limit=True, grad_limit_values=[0.05, 0.01],
+                                                               grad_limit_iters=[3]))):
+        g = torch.Generator().manual_seed(11)
+        p = torch.nn.Parameter(torch.randn(257, 3, generator=g, dtype=torch.float64))
+        opt = ro.AdamUniform([p], **kw)
+        grads, traj = [], []
+        for it in range(6):
+            gr = torch.randn(257, 3, generator=g, dtype=torch.float64) * (10.0 ** (it - 2))
+            p.grad = gr.clone()
+            opt.step()
+            grads.append(gr.numpy().copy())
+            traj.append(p.detach().numpy().copy())
+        out[f"{name}_p0"] = (traj[0] * 0 + 0)  # placeholder replaced below
+        out[f"{name}_grads"] = np.stack(grads)
+        out[f"{name}_traj"] = np.stack(traj)
+    g = torch.Generator().manual_seed(11)
+    out["p0"] = torch.randn(257, 3, generator=g, dtype=torch.float64).numpy()
+    for k in ("plain_p0", "limited_p0"):
+        out.pop(k)
+    np.savez_compressed(os.path.join(HERE, "adam_uniform_golden.npz"), **out)
     print("wrote", os.listdir(HERE))
 
 

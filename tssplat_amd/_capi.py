@@ -85,6 +85,8 @@ SIGNATURES = {
     "tsamd_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "tsamd_adam_uniform_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                        C.c_float, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
     "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
 }

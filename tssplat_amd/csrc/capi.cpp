@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -452,6 +453,18 @@ int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, in
 {
     if (n < 0 || (n > 0 && (!in_dev || !scalar_dev || !out_dev))) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
     TSAMD_HIP(tsamd::launch_scale(in_dev, scalar_dev, out_dev, n, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_adam_uniform_step(float *param_dev, const float *grad_dev, float *g1_dev, float *g2_dev, int64_t n, float lr,
+                            float beta1, float beta2, int64_t step, float grad_limit, void *workspace_dev, void *stream)
+{
+    if (n < 0 || step < 1 || (n > 0 && (!param_dev || !grad_dev || !g1_dev || !g2_dev || !workspace_dev)))
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument, negative size or step < 1");
+    const float bias1 = float(1.0 - std::pow(double(beta1), double(step)));   // optimizer.py:67-68
+    const float bias2 = float(1.0 - std::pow(double(beta2), double(step)));
+    TSAMD_HIP(tsamd::launch_adam_uniform(param_dev, grad_dev, g1_dev, g2_dev, n, lr, beta1, beta2, bias1, bias2, grad_limit,
+                                         workspace_dev, static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }
 

@@ -38,6 +38,8 @@ struct EvalArgs {
 hipError_t launch_eval(const EvalArgs &a, hipStream_t stream, hipEvent_t *ev = nullptr);
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
+hipError_t launch_adam_uniform(float *p, const float *grad, float *g1, float *g2, int64_t n, float lr, float b1, float b2,
+                               float bias1, float bias2, float limit, void *workspace, hipStream_t stream);
 hipError_t configure_kernels(int lds_bytes);
 
 }  // namespace tsamd

@@ -668,6 +668,59 @@ __global__ __launch_bounds__(256) void clamp_kernel(float *g, int64_t n, const u
     for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) g[i] *= f;
 }
 
+// ---- AdamUniform (reference utils/optimizer.py:38-89), two passes, no host sync ----
+// pass 1: moments in place (optimizer.py:61-62) + max g2 and max |g1| (the two global maxima the reference
+//         takes with .max(), :74 and :84, are monotone in the bias-corrected values)
+__global__ __launch_bounds__(256) void adam_moments_kernel(const float *grad, float *g1, float *g2, int64_t n, float b1,
+                                                           float b2, unsigned int *ws)
+{
+    __shared__ float red[2 * (256 / kWave)];
+    float mx2 = 0.f, mx1 = 0.f;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
+        const float g = grad[i];
+        const float a = g1[i] * b1 + g * (1.f - b1);
+        const float b = g2[i] * b2 + (g * g) * (1.f - b2);
+        g1[i] = a;
+        g2[i] = b;
+        mx1 = fmaxf(mx1, fabsf(a));
+        mx2 = fmaxf(mx2, b);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        mx1 = fmaxf(mx1, __shfl_down(mx1, off, kWave));
+        mx2 = fmaxf(mx2, __shfl_down(mx2, off, kWave));
+    }
+    const int wave = threadIdx.x / kWave;
+    if (threadIdx.x % kWave == 0) {
+        red[2 * wave] = mx1;
+        red[2 * wave + 1] = mx2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 256 / kWave; ++w) {
+            mx1 = fmaxf(mx1, red[2 * w]);
+            mx2 = fmaxf(mx2, red[2 * w + 1]);
+        }
+        atomicMax(ws, __float_as_uint(mx1));      // non-negative floats order like their bit patterns
+        atomicMax(ws + 1, __float_as_uint(mx2));
+    }
+}
+
+// pass 2: gr = m1 / (1e-8 + max sqrt(m2)) (:74), optional max-abs clamp to `limit` (:84-86), p -= lr * gr (:88)
+__global__ __launch_bounds__(256) void adam_apply_kernel(float *p, const float *g1, int64_t n, float lr, float bias1,
+                                                         float bias2, float limit, const unsigned int *ws)
+{
+    const float mx1 = __uint_as_float(ws[0]) / bias1;             // max |m1|
+    const float denom = 1e-8f + sqrtf(__uint_as_float(ws[1]) / bias2);
+    float scale = 1.f / denom;
+    const float s = mx1 / denom;                                  // max |gr|
+    if (limit > 0.f && s > limit) scale *= limit / s;
+    const float k = lr * scale / bias1;
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) p[i] -= k * g1[i];
+}
+
 int grid_for(int64_t n, int per_block, int cap)
 {
     int64_t b = (n + per_block - 1) / per_block;
@@ -786,6 +839,19 @@ hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(scale_kernel, dim3(unsigned(grid_for(n, 1024, 2048))), dim3(256), 0, stream, in, scalar, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam_uniform(float *p, const float *grad, float *g1, float *g2, int64_t n, float lr, float b1, float b2,
+                               float bias1, float bias2, float limit, void *workspace, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    unsigned int *ws = static_cast<unsigned int *>(workspace);
+    hipError_t e = hipMemsetAsync(ws, 0, 2 * sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    const int g = grid_for(n, 1024, 4096);
+    hipLaunchKernelGGL(adam_moments_kernel, dim3(unsigned(g)), dim3(256), 0, stream, grad, g1, g2, n, b1, b2, ws);
+    hipLaunchKernelGGL(adam_apply_kernel, dim3(unsigned(g)), dim3(256), 0, stream, p, g1, n, lr, bias1, bias2, limit, ws);
     return hipGetLastError();
 }
 
