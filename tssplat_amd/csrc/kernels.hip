@@ -676,15 +676,31 @@ __global__ __launch_bounds__(256) void adam_moments_kernel(const float *grad, fl
 {
     __shared__ float red[2 * (256 / kWave)];
     float mx2 = 0.f, mx1 = 0.f;
-    const int64_t stride = int64_t(gridDim.x) * 256;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) {
-        const float g = grad[i];
-        const float a = g1[i] * b1 + g * (1.f - b1);
-        const float b = g2[i] * b2 + (g * g) * (1.f - b2);
-        g1[i] = a;
-        g2[i] = b;
+    const int64_t stride = int64_t(gridDim.x) * 256, gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    auto upd = [&](float g, float &a, float &b) {
+        a = a * b1 + g * (1.f - b1);
+        b = b * b2 + (g * g) * (1.f - b2);
         mx1 = fmaxf(mx1, fabsf(a));
         mx2 = fmaxf(mx2, b);
+    };
+    // 16 B per lane (torch allocations are 16-B aligned; the tail and odd alignments take the scalar loop)
+    const bool vec = ((reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(g1) | reinterpret_cast<uintptr_t>(g2)) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    for (int64_t i = gid; i < n4; i += stride) {
+        const float4 g = reinterpret_cast<const float4 *>(grad)[i];
+        float4 a = reinterpret_cast<float4 *>(g1)[i], b = reinterpret_cast<float4 *>(g2)[i];
+        upd(g.x, a.x, b.x);
+        upd(g.y, a.y, b.y);
+        upd(g.z, a.z, b.z);
+        upd(g.w, a.w, b.w);
+        reinterpret_cast<float4 *>(g1)[i] = a;
+        reinterpret_cast<float4 *>(g2)[i] = b;
+    }
+    for (int64_t i = 4 * n4 + gid; i < n; i += stride) {
+        float a = g1[i], b = g2[i];
+        upd(grad[i], a, b);
+        g1[i] = a;
+        g2[i] = b;
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
@@ -717,8 +733,19 @@ __global__ __launch_bounds__(256) void adam_apply_kernel(float *p, const float *
     const float s = mx1 / denom;                                  // max |gr|
     if (limit > 0.f && s > limit) scale *= limit / s;
     const float k = lr * scale / bias1;
-    const int64_t stride = int64_t(gridDim.x) * 256;
-    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += stride) p[i] -= k * g1[i];
+    const int64_t stride = int64_t(gridDim.x) * 256, gid = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g1)) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    for (int64_t i = gid; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4 *>(p)[i];
+        const float4 a = reinterpret_cast<const float4 *>(g1)[i];
+        v.x -= k * a.x;
+        v.y -= k * a.y;
+        v.z -= k * a.z;
+        v.w -= k * a.w;
+        reinterpret_cast<float4 *>(p)[i] = v;
+    }
+    for (int64_t i = 4 * n4 + gid; i < n; i += stride) p[i] -= k * g1[i];
 }
 
 int grid_for(int64_t n, int per_block, int cap)
