@@ -168,7 +168,7 @@ def _check_input(x: torch.Tensor, ts: TetSpheres) -> torch.Tensor:
         raise RuntimeError("input must be float32")
     if x.numel() != ts.n3:
         raise RuntimeError(f"input has {x.numel()} elements, expected {ts.n3} (= 3 * n_vertices)")
-    return x.detach().contiguous()                     # tet_spheres_cuda.cu:124
+    return x if x.is_contiguous() else x.detach().contiguous()   # tet_spheres_cuda.cu:124 (only data_ptr is used)
 
 
 def _cache_key(x: torch.Tensor, c1: float, c2: float, order: int):
@@ -199,9 +199,13 @@ def backward(gradH: torch.Tensor, input: torch.Tensor, tet_sph: TetSpheres, c1: 
     """``gradH * dE/dx`` with the shape/dtype/device of ``input`` (tet_spheres_cuda.cu:197-263)."""
     h = tet_sph._handle()
     x = _check_input(input, tet_sph)
-    if not isinstance(gradH, torch.Tensor):
-        gradH = torch.tensor(float(gradH), dtype=torch.float32)
-    go = gradH.detach().to(device=x.device, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
+    if isinstance(gradH, torch.Tensor) and gradH.device == x.device and gradH.dtype == torch.float32 \
+            and gradH.numel() == 1:
+        go = gradH                                      # the usual case: autograd hands over a device scalar
+    else:
+        if not isinstance(gradH, torch.Tensor):
+            gradH = torch.tensor(float(gradH), dtype=torch.float32)
+        go = gradH.detach().to(device=x.device, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
     stream = _stream_ptr(x.device)
     cached = tet_sph._cache
     tet_sph._cache = None
