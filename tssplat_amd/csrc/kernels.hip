@@ -94,11 +94,16 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
             F[3 * i + j] = Ds[3 * i + 0] * dm[j][p] + Ds[3 * i + 1] * dm[3 + j][p] + Ds[3 * i + 2] * dm[6 + j][p];
 }
 
-// One 48-byte LDS slot holds F (9 floats, 3 pad), later H, later the 4 x 3 vertex forces.
+// One 48-byte LDS record holds F (later H) as two float quads plus a tail quad, later the 4 x 3 vertex
+// forces.  The ninth matrix entry sits in the tail quad at position tail_pos(idx): with a fixed position
+// the 48-byte stride would fold every 4-byte neighbour gather onto 8 of the 32 banks; rotating it with
+// bits 3-4 of the record index spreads those gathers over all banks.
 struct Mat9 {
     v2f p01, p23, p45, p67;  // packed pairs: v_pk_{mul,add,fma}_f32 work on these at twice the scalar rate
     float p8;
 };
+
+__device__ __forceinline__ uint32_t tail_byte(uint32_t idx) { return 32u + ((idx >> 1) & 12u); }
 
 __device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx)
 {
@@ -106,13 +111,12 @@ __device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx
     const v4f a = *reinterpret_cast<const v4f *>(s), b = *reinterpret_cast<const v4f *>(s + 16);
     Mat9 m;
     m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
-    m.p8 = *reinterpret_cast<const float *>(s + 32);
+    m.p8 = *reinterpret_cast<const float *>(s + tail_byte(idx));
     return m;
 }
 
 // Own-slot variant: consecutive lanes walk consecutive records, where 16-byte accesses are
-// conflict-free but a 4-byte access at +32 is not (48 B stride folds 32 lanes onto 8 banks), so the
-// ninth float travels as a full quad too.
+// conflict-free and 4-byte ones are not, so the tail travels as a full quad and the lane picks its entry.
 __device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t idx)
 {
     const unsigned char *s = lds + idx * 48u;
@@ -121,16 +125,19 @@ __device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t
     asm volatile("" : : "v"(c));
     Mat9 m;
     m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
-    m.p8 = __uint_as_float(c.x);
+    const uint32_t r = (idx >> 3) & 3u;
+    const uint32_t lo = (r & 1u) ? c.y : c.x, hi = (r & 1u) ? c.w : c.z;
+    m.p8 = __uint_as_float((r & 2u) ? hi : lo);
     return m;
 }
 
 __device__ __forceinline__ void store_slot(unsigned char *lds, uint32_t idx, const float *m)
 {
     unsigned char *s = lds + idx * 48u;
+    const uint32_t r = (idx >> 3) & 3u;
     *reinterpret_cast<v4f *>(s) = v4f{m[0], m[1], m[2], m[3]};
     *reinterpret_cast<v4f *>(s + 16) = v4f{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<v4f *>(s + 32) = v4f{m[8], 0.f, 0.f, 0.f};
+    *reinterpret_cast<v4f *>(s + 32) = v4f{r == 0u ? m[8] : 0.f, r == 1u ? m[8] : 0.f, r == 2u ? m[8] : 0.f, r == 3u ? m[8] : 0.f};
 }
 
 // acc = deg * own - sum of the four neighbours (zero slot for a missing one)
