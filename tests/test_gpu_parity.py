@@ -257,6 +257,40 @@ def test_config3_one_million_tets_properties(ext):
     assert np.linalg.norm(np.concatenate([ga, gb]) - g) <= 1e-5 * np.linalg.norm(g)
 
 
+def test_config4_full_size_properties(ext):
+    """BASELINE config 4 / the bench workload (512 x kuhn19 = 21 070 848 tets): C-oracle parity at full
+    size, plus size-independent properties: bit-identical repeats, zero net force and zero net torque per
+    sphere (the energy is invariant under rigid motions), and a checksum of per-sphere checksums."""
+    from tssplat_amd import scenes
+    from oracle import c_oracle
+    S = 512
+    sc = scenes.make_scene("kuhn19", S)
+    assert sc.n_tets == 21_070_848 and sc.n_vertices == 4_096_000
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    x = scenes.deform(sc, 0.02)
+    c1, c2 = 2e-4 / S, 2e-4
+    e, g = _eval_gpu(ext, ts, x, c1, c2, 2)
+    e2, g2 = _eval_gpu(ext, ts, x, c1, c2, 2)
+    assert e == e2 and np.array_equal(g, g2), "evaluation must be deterministic (fixed reduction order)"
+    E, Es, Eb, go = c_oracle.energy_and_grad(sc.rest, sc.tets, x, c1, c2, 2)
+    assert abs(e - E) <= 2e-5 * abs(E)
+    assert np.linalg.norm(g - go) <= 5e-4 * np.linalg.norm(go)
+    # per-sphere slices: same bound sphere by sphere (a single wrong tile cannot hide in the global norm)
+    nv = sc.n_vertices // S
+    gs, gos = g.reshape(S, nv, 3), go.reshape(S, nv, 3)
+    err = np.linalg.norm((gs - gos).reshape(S, -1), axis=1)
+    ref = np.linalg.norm(gos.reshape(S, -1), axis=1)
+    assert np.all(err <= 2e-3 * ref + 1e-12), f"worst sphere: {np.max(err / ref):.2e}"
+    # rigid-motion invariance: net force and net torque of every sphere vanish
+    xs = x.astype(np.float64).reshape(S, nv, 3)
+    scale = np.abs(gs).sum(axis=1).max(axis=1)                           # per-sphere sum of |force|
+    assert np.all(np.abs(gs.sum(axis=1)).max(axis=1) <= 1e-4 * scale)
+    torque = np.cross(xs - xs.mean(axis=1, keepdims=True), gs).sum(axis=1)
+    assert np.all(np.abs(torque).max(axis=1) <= 1e-4 * scale)
+    # checksum of checksums against the oracle
+    assert abs(gs.sum(axis=(1, 2)).sum() - gos.sum(axis=(1, 2)).sum()) <= 1e-4 * np.abs(gos).sum() / np.sqrt(go.size)
+
+
 def test_degenerate_inputs(ext):
     """Empty batches and vertices no tet references: energy 0, gradient 0 (never uninitialised)."""
     from tssplat_amd import scenes

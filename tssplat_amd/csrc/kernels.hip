@@ -95,7 +95,7 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
 }
 
 // One 48-byte LDS record holds F (later H) as two float quads plus a tail quad, later the 4 x 3 vertex
-// forces.  The ninth matrix entry sits in the tail quad at position tail_pos(idx): with a fixed position
+// forces.  The ninth matrix entry sits in the tail quad at byte tail_byte(idx): with a fixed position
 // the 48-byte stride would fold every 4-byte neighbour gather onto 8 of the 32 banks; rotating it with
 // bits 3-4 of the record index spreads those gathers over all banks.
 struct Mat9 {
@@ -115,29 +115,17 @@ __device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx
     return m;
 }
 
-// Own-slot variant: consecutive lanes walk consecutive records, where 16-byte accesses are
-// conflict-free and 4-byte ones are not, so the tail travels as a full quad and the lane picks its entry.
-__device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t idx)
-{
-    const unsigned char *s = lds + idx * 48u;
-    const v4f a = *reinterpret_cast<const v4f *>(s), b = *reinterpret_cast<const v4f *>(s + 16);
-    const v4u c = *reinterpret_cast<const v4u *>(s + 32);
-    asm volatile("" : : "v"(c));
-    Mat9 m;
-    m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
-    const uint32_t r = (idx >> 3) & 3u;
-    const uint32_t lo = (r & 1u) ? c.y : c.x, hi = (r & 1u) ? c.w : c.z;
-    m.p8 = __uint_as_float((r & 2u) ? hi : lo);
-    return m;
-}
+// Own-slot accesses: consecutive lanes walk consecutive records; 16-byte accesses of the two quads are
+// conflict-free, and so are the 4-byte ones of the rotated tail entry (32 consecutive records -> 32 banks).
+__device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t idx) { return load_slot(lds, idx); }
 
+// Stores cost 2 cycles per source dword on the VGPR -> LDS path, so the tail goes out as one dword, not a quad.
 __device__ __forceinline__ void store_slot(unsigned char *lds, uint32_t idx, const float *m)
 {
     unsigned char *s = lds + idx * 48u;
-    const uint32_t r = (idx >> 3) & 3u;
     *reinterpret_cast<v4f *>(s) = v4f{m[0], m[1], m[2], m[3]};
     *reinterpret_cast<v4f *>(s + 16) = v4f{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<v4f *>(s + 32) = v4f{r == 0u ? m[8] : 0.f, r == 1u ? m[8] : 0.f, r == 2u ? m[8] : 0.f, r == 3u ? m[8] : 0.f};
+    *reinterpret_cast<float *>(s + tail_byte(idx)) = m[8];
 }
 
 // acc = deg * own - sum of the four neighbours (zero slot for a missing one)
