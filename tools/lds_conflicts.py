@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Host-side estimate of the tile kernel's LDS bank-conflict cycles, from the plan alone (no GPU).
+
+Replays the addresses of the data-dependent LDS reads (neighbour gathers of passes 2/3, per-vertex force
+gather) through the lane-group / bank rules of MI355X_MICROARCH.md (LDS section) and reports base cycles
+and extra (conflict) cycles per tile slot.  Used to compare ordering heuristics in csrc/plan.cpp offline.
+
+    python tools/lds_conflicts.py [--scene kuhn19 --spheres 1] [--no-conflict-aware]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+
+G128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27],
+        [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+G128 = G128 + [[l + 32 for l in g] for g in G128]
+
+
+def group_cycles(keys, addrs):
+    """LDS cycles of one lane group: max over banks of the number of distinct addresses on that bank."""
+    if len(keys) == 0:
+        return 0
+    pairs = np.unique(np.stack([keys, addrs], axis=1), axis=0)
+    return int(np.bincount(pairs[:, 0]).max())
+
+
+def tile_conflicts(T, spt):
+    sp = T["s_pad"]
+    nq = sp // spt
+    pl = T["planes"]
+    owned_slot = (pl[0] & 0x8000) != 0
+    nb = np.stack([pl[2] & 0x1fff, (pl[2] >> 16) & 0x1fff, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
+    res = dict(g128_base=0, g128_extra=0, g32_base=0, g32_extra=0, v_base=0, v_extra=0)
+    for p in range(spt):
+        for wbase in range(0, nq, 64):
+            lanes = np.arange(wbase, min(wbase + 64, nq))
+            slots = spt * lanes + p
+            for owned_only in (True, False):                 # pass 2 (owned lanes), pass 3 (all lanes)
+                act = owned_slot[slots] if owned_only else np.ones(len(slots), bool)
+                if not act.any():
+                    continue
+                for k in range(4):
+                    idx = nb[slots, k]
+                    for g in G128:                            # the two b128 quads of the record
+                        sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) in g and act[i]]
+                        if not sel:
+                            continue
+                        c = group_cycles((3 * idx[sel]) % 16, idx[sel])
+                        res["g128_base"] += 2
+                        res["g128_extra"] += 2 * (c - 1)
+                    for h in range(2):                        # the rotated tail dword
+                        sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) // 32 == h and act[i]]
+                        if not sel:
+                            continue
+                        ii = idx[sel]
+                        bank = (12 * ii + 8 + ((ii >> 3) & 3)) % 32
+                        c = group_cycles(bank, ii)
+                        res["g32_base"] += 1
+                        res["g32_extra"] += c - 1
+    # per-vertex gather: lanes 2v+h, chunk 2j+h, entry q, component c
+    inc, off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
+    nv = T["n_verts"]
+    for wb in range(0, 2 * nv, 64):
+        us = np.arange(wb, min(wb + 64, 2 * nv))
+        v, h = us >> 1, us & 1
+        nch = off[v + 1] - off[v]
+        steps = int(np.max((nch - h + 1) // 2))
+        for j in range(steps):
+            ch = off[v] + 2 * j + h
+            ok = ch < off[v + 1]
+            for q in range(4):
+                e = np.where(ok, inc[np.minimum(4 * ch + q, len(inc) - 1)], (T["s_pad"] << 2) | 1)
+                for comp in range(3):
+                    for half in range(2):
+                        sel = (us - wb) // 32 == half
+                        if not sel.any():
+                            continue
+                        c = group_cycles((3 * e[sel] + comp) % 32, e[sel])
+                        res["v_base"] += 1
+                        res["v_extra"] += c - 1
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="kuhn19")
+    ap.add_argument("--spheres", type=int, default=1)
+    ap.add_argument("--no-conflict-aware", action="store_true")
+    ap.add_argument("--max-tiles", type=int, default=12)
+    args = ap.parse_args()
+    from tssplat_amd import scenes, tet_spheres_ext as X
+    import tile_emulator as TE
+    sc = scenes.make_scene(args.scene, args.spheres)
+    ts = X.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True,
+                      debug_shuffle=2 if args.no_conflict_aware else 0)
+    spt = ts.plan_info()["slots_per_thread"]
+    tot, slots = {}, 0
+    for i, T in enumerate(TE.plan_tiles(ts)):
+        if i >= args.max_tiles:
+            break
+        r = tile_conflicts(T, spt)
+        slots += T["n_slots"]
+        for k, val in r.items():
+            tot[k] = tot.get(k, 0) + val
+    print(f"{args.spheres} x {args.scene}: {slots} slots in the first {min(i + 1, args.max_tiles)} tiles; LDS cycles per 64 slots:")
+    for k in ("g128", "g32", "v"):
+        b, e = tot[k + "_base"] * 64 / slots, tot[k + "_extra"] * 64 / slots
+        print(f"  {k:5s} base {b:7.1f}  conflict extra {e:7.1f}  ({e / b:.2f}x)")
+
+
+if __name__ == "__main__":
+    main()

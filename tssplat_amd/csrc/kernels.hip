@@ -218,6 +218,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     const uint32_t ZS = uint32_t(td.s_pad);
     const bool active = tid < nq;
     const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);  // 13 planes of s_pad dwords
+    // (non-temporal loads of the planes were measured: tile kernel +1.4 %, finish kernel -4 %, net slower)
     auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * tid); };
     auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * tid); };
     STAMP(0);
@@ -320,9 +321,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     float nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t warm[kPlanes];
     if (WITH_GRAD) {
-        // vertex incidence lists (thread t gathers local vertex t): fetch the first kPre chunks now so
-        // that their HBM latency hides behind pass 3
-        constexpr int kPre = 6;
+        // vertex incidence lists: lanes 2v and 2v+1 gather local vertex v, one taking the even chunks of its
+        // list and one the odd ones.  Each fetches its first kPre chunks now so that their HBM latency hides
+        // behind pass 3.
+        constexpr int kPre = 3;
         const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kPlanes * td.s_pad);
         const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
         const uint32_t pad16 = (ZS << 2) | 1u;
@@ -386,12 +388,15 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
-        if (tid < td.n_verts) {
-            pc0 = inc_off[tid];
-            pc1 = inc_off[tid + 1];
+        int32_t dst_row = 0;  // where this lane's vertex goes: fetched here, a whole phase ahead of its use
+        if (tid < 2 * td.n_verts) {
+            const int v = tid >> 1;
+            pc0 = inc_off[v] + (tid & 1);
+            pc1 = inc_off[v + 1];
+            dst_row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
 #pragma unroll
             for (int q = 0; q < kPre; ++q)
-                pre[q] = pc0 + q < pc1 ? inc[pc0 + q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
+                pre[q] = pc0 + 2 * q < pc1 ? inc[pc0 + 2 * q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
         }
         // ---- persistent walk: start fetching the next tile's vertex positions (4 registers) ----
         if (has_next) {
@@ -438,8 +443,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         // Entry e = (lds slot << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
         // point into the all-zero slot.  Exclusive vertices go straight to grad, vertices shared with
         // other tiles to the staging rows, which the finish kernel sums in plan order.
+        // The plan sorts a tile's vertices by list length, so the lanes of one wave need about the same
+        // number of chunks and a wave stops at its own longest list.
         const float gscale = a.grad_out ? *as_global(a.grad_out) : 1.f;
-        for (int v = tid; v < td.n_verts; v += nthr) {
+        for (int u = tid; u < 2 * td.n_verts; u += nthr) {
+            const int v = u >> 1;
             float gx = 0.f, gy = 0.f, gz = 0.f;
             auto gather4 = [&](const v2u w) {
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
@@ -451,21 +459,31 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     gz += f[2];
                 }
             };
+            int32_t row = dst_row;
             if (!DBG(DBG_SKIP_VGATHER)) {
                 int c, c1;
-                if (v == tid) {  // prefetched chunks; the ones past the list end are all-padding
-#pragma unroll
-                    for (int q = 0; q < kPre; ++q) gather4(pre[q]);
-                    c = pc0 + kPre;
+                if (u == tid) {  // prefetched chunks; a wave skips the steps none of its lanes needs
+                    c = pc0;
                     c1 = pc1;
+#pragma unroll
+                    for (int q = 0; q < kPre; ++q) {
+                        if (__builtin_amdgcn_ballot_w64(c < c1) == 0) break;
+                        gather4(pre[q]);
+                        c += 2;
+                    }
                 } else {
-                    c = inc_off[v];
+                    c = inc_off[v] + (u & 1);
                     c1 = inc_off[v + 1];
+                    row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
                 }
-                for (; c < c1; ++c) gather4(inc[c]);
+                for (; c < c1; c += 2) gather4(inc[c]);
             }
-            GLOBAL_AS float *dst = v < td.n_excl ? g_grad + size_t(g_gvid[td.vert_off + v]) * 3
-                                                 : g_stage + size_t(g_sdst[td.stage_off + (v - td.n_excl)]) * 3;
+            // even lane + odd lane (quad_perm [1,0,3,2]); both lanes end up with the same sum
+            gx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gx), 0xB1, 0xf, 0xf, false));
+            gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xf, 0xf, false));
+            gz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0xB1, 0xf, 0xf, false));
+            if (u & 1) continue;
+            GLOBAL_AS float *dst = (v < td.n_excl ? g_grad : g_stage) + size_t(row) * 3;
             const float sc = v < td.n_excl ? gscale : 1.f;
             if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
