@@ -76,12 +76,6 @@ struct tsamd_handle {
     float *d_energy_scratch = nullptr;
     // optional kernel timing (bench.py roofline leg)
     int dbg = 0;  // kernel ablation switches, tools/ablate.py only
-    // Experimental: resident workgroups walking several tiles with next-tile prefetch
-    // (TSSPLAT_AMD_PERSISTENT=1).  Measured slower than one workgroup per tile (0.65 vs 0.54 ms on the
-    // 21 M-tet scene): two workgroups per CU already overlap stream and compute, and resident
-    // workgroups run in lockstep.  Off by default.
-    bool persistent = false;
-    int persistent_blocks = 0;  // 2 per CU
     long long *d_clk = nullptr;  // 16 clock stamps per tile (ablation builds)
     bool timing = false;
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
@@ -154,9 +148,6 @@ int to_device(tsamd_handle *h, int device)
         const int32_t lds_p = int32_t(tsamd::tile_lds_bytes((P.max_slots + 3) & ~3, P.max_verts));
         TSAMD_HIP(tsamd::configure_kernels(std::max(P.lds_bytes, lds_p <= 160 * 1024 ? lds_p : P.lds_bytes)));
     }
-    h->persistent_blocks = 2 * prop.multiProcessorCount;
-    if (const char *env = std::getenv("TSSPLAT_AMD_PERSISTENT")) h->persistent = std::atoi(env) != 0;
-    if (const char *env = std::getenv("TSSPLAT_AMD_PERSISTENT_BLOCKS")) h->persistent_blocks = std::max(8, std::atoi(env));
     return TSAMD_OK;
 }
 
@@ -237,10 +228,6 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
     a.spt = h->plan.spt;
-    a.sa_max = ((h->plan.max_slots + 3) & ~3) + 4;
-    a.vp_max = (h->plan.max_verts + 3) & ~3;
-    a.lds_bytes_persistent = int32_t(tsamd::tile_lds_bytes((h->plan.max_slots + 3) & ~3, h->plan.max_verts));
-    a.persistent_blocks = h->persistent ? h->persistent_blocks : 0;
     a.dbg = h->dbg;
     a.clk = h->d_clk;
     a.x = x;

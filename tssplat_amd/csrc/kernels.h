@@ -18,8 +18,6 @@ struct EvalArgs {
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
     int32_t spt = 4;        // slots per thread the plan was laid out for
-    int32_t sa_max = 0, vp_max = 0, lds_bytes_persistent = 0;  // LDS layout covering the plan's largest tile
-    int32_t persistent_blocks = 0;  // workgroups of a persistent launch (0 = one workgroup per tile)
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
     long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
     // per evaluation

@@ -157,7 +157,6 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
-    int sa_max, vp_max;  // persistent launches: LDS layout for the largest tile of the plan
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
     long long *clk;  // ablation builds: 16 shader-clock stamps per tile (phase boundaries of thread 0)
 };
@@ -186,12 +185,10 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
 // SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
 // SIMD): <1024, 4> gives 128 VGPRs and one workgroup per CU, <768, 6> 80 VGPRs and two.
-// Everything one workgroup does for one tile.  `next` >= 0 (persistent walk) names the tile this workgroup
-// takes afterwards: its vertex positions are staged into xs as soon as this tile is done with them, and
-// its planes are touched so that the next call streams them from L2 rather than HBM.
+// Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
+// prefetch, and touching a successor tile's planes into L2, were both measured slower: DESIGN.md section 8.)
 template <bool WITH_GRAD, int SPT>
-__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int next, const int SA, const int VP,
-                                          const bool stage_self)
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
 {
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
     // out-of-line copy would turn into a flat_* instruction
@@ -234,13 +231,12 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     }
     if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
-    if (stage_self) {  // stage this tile's vertex positions (behind the plane loads just issued)
-        for (int v = tid; v < td.n_verts; v += nthr) {
-            const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
-            reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        }
-        __syncthreads();
+    // stage this tile's vertex positions (behind the plane loads just issued)
+    for (int v = tid; v < td.n_verts; v += nthr) {
+        const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
+        reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
     }
+    __syncthreads();
     STAMP(1);
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
         float chk = dm[0][0] + dm[4][1] + dm[8][SPT - 1] + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
@@ -316,10 +312,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     __syncthreads();  // every read of F is done; overwrite it with H in place
     STAMP(3);  // pass 2 done
 
-    const bool has_next = next >= 0;
-    TileDesc tdn = td;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    uint32_t warm[kPlanes];
     if (WITH_GRAD) {
         // vertex incidence lists: lanes 2v and 2v+1 gather local vertex v, one taking the even chunks of its
         // list and one the odd ones.  Each fetches its first kPre chunks now so that their HBM latency hides
@@ -398,26 +390,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             for (int q = 0; q < kPre; ++q)
                 pre[q] = pc0 + 2 * q < pc1 ? inc[pc0 + 2 * q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
         }
-        // ---- persistent walk: start fetching the next tile's vertex positions (4 registers) ----
-        if (has_next) {
-            tdn = a.tiles[next];
-            if (tid < tdn.n_verts) {
-                const size_t gv = size_t(g_gvid[tdn.vert_off + tid]) * 3;
-                nx = g_x[gv];
-                ny = g_x[gv + 1];
-                nz = g_x[gv + 2];
-            }
-        }
         STAMP(5);  // pass 3 compute done (this wave)
         __syncthreads();
         STAMP(6);  // all waves done with H and with the staged positions
-        if (has_next) {  // xs is free now: stage the next tile's positions
-            if (tid < tdn.n_verts) reinterpret_cast<float4 *>(xs)[tid] = make_float4(nx, ny, nz, 0.f);
-            for (int v = tid + nthr; v < tdn.n_verts; v += nthr) {
-                const size_t gv = size_t(g_gvid[tdn.vert_off + v]) * 3;
-                reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-            }
-        }
         // ---- write the vertex forces: record = (f0.xyz, f1.xyz, f2.xyz, f3.xyz), f0 = -(f1 + f2 + f3) ----
         if (active) {
 #pragma unroll
@@ -427,13 +402,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 *reinterpret_cast<v4f *>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
                 *reinterpret_cast<v4f *>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
                 *reinterpret_cast<v4f *>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
-            }
-        }
-        if (has_next) {  // touch the next tile's planes so that its stream phase hits L2 instead of HBM
-            const GLOBAL_AS uint32_t *pln = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + tdn.blob_off);
-            if (tid < tdn.s_pad / SPT) {
-#pragma unroll
-                for (int q = 0; q < kPlanes; ++q) warm[q] = pln[q * tdn.s_pad + SPT * tid];
             }
         }
         __syncthreads();
@@ -518,43 +486,22 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         g_partials[2 * size_t(tile) + 1] = b;
     }
     STAMP(9);
-    if (has_next && tid < tdn.s_pad / SPT) {  // retire the warm-up loads
-#pragma unroll
-        for (int q = 0; q < kPlanes; ++q) asm volatile("" : : "v"(warm[q]));
-    }
 }
 
-// PERSIST: the workgroup walks a strided sequence of tiles and hides the next tile's stream phase behind the
-// current tile's tail (positions prefetched into LDS, planes touched into L2).  No per-lane state is carried
-// from one tile to the next, which keeps the register allocation of the loop body at the one-tile level.
-template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool PERSIST>
+template <bool WITH_GRAD, int BLOCK, int SPT, int WPE>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
-    static_assert(!PERSIST || WITH_GRAD, "the persistent walk is only built for the fused kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
     // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2 and the halo
     // planes two neighbouring tiles both read are served from it.
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int tile_step = PERSIST ? int(gridDim.x >> 3) : a.tiles_per_xcd;
     const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
-    int tile = xcd * a.tiles_per_xcd + jb;
+    const int tile = xcd * a.tiles_per_xcd + jb;
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
-
     const TileDesc td0 = a.tiles[tile];
-    const int SA = PERSIST ? a.sa_max : td0.s_pad + 4;
-    const int VP = PERSIST ? a.vp_max : (td0.n_verts + 3) & ~3;
-    if (!PERSIST) {
-        tile_body<WITH_GRAD, SPT>(a, tile, -1, SA, VP, true);
-    } else {
-        for (bool first = true;; first = false) {
-            const int next = tile + tile_step < tile_end ? tile + tile_step : -1;
-            tile_body<WITH_GRAD, SPT>(a, tile, next, SA, VP, first);  // inlined: no per-lane state is carried between tiles
-            if (next < 0) break;
-            tile = next;
-        }
-    }
+    tile_body<WITH_GRAD, SPT>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
 }
 
 struct FinishArgs {
@@ -773,13 +720,12 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
 
 hipError_t configure_kernels(int lds_bytes)
 {
-    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6, false>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, true>)};
+    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -821,24 +767,16 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         const dim3 block(unsigned(e.block_threads));
         // 2 slots per lane and two workgroups per CU (<= 80 KiB LDS, <= 768 threads): the 80-VGPR build
         const bool two_per_cu = e.spt == 2 && e.block_threads <= 768 && e.lds_bytes <= 80 * 1024;
-        const bool persist = e.grad && two_per_cu && e.persistent_blocks > 0 && e.lds_bytes_persistent <= 80 * 1024 &&
-                             e.n_tiles > e.persistent_blocks;
-        k.sa_max = e.sa_max;
-        k.vp_max = e.vp_max;
-#define TSAMD_LAUNCH(G, B, S, W, P) \
-    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W, P>), grid, block, size_t(lds), stream, k)
-        size_t lds = size_t(e.lds_bytes);
-        dim3 grid(unsigned(8 * k.tiles_per_xcd));
-        if (persist) {
-            lds = size_t(e.lds_bytes_persistent);
-            grid = dim3(unsigned((e.persistent_blocks + 7) / 8 * 8));
-            TSAMD_LAUNCH(true, 768, 2, 6, true);
-        } else if (e.spt == 2 && two_per_cu) {
-            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6, false); else TSAMD_LAUNCH(false, 768, 2, 6, false);
+#define TSAMD_LAUNCH(G, B, S, W) \
+    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(lds), stream, k)
+        const size_t lds = size_t(e.lds_bytes);
+        const dim3 grid(unsigned(8 * k.tiles_per_xcd));
+        if (e.spt == 2 && two_per_cu) {
+            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
         } else if (e.spt == 2) {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4, false); else TSAMD_LAUNCH(false, 1024, 2, 4, false);
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4); else TSAMD_LAUNCH(false, 1024, 2, 4);
         } else {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4, false); else TSAMD_LAUNCH(false, 1024, 4, 4, false);
+            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4); else TSAMD_LAUNCH(false, 1024, 4, 4);
         }
 #undef TSAMD_LAUNCH
         hipError_t err = hipGetLastError();
