@@ -181,6 +181,40 @@ int tsamd_adam_uniform_step(float *param_dev, const float *grad_dev, float *g1_d
                             float lr, float beta1, float beta2, int64_t step, float grad_limit,
                             void *workspace_dev, void *stream);
 
+/*
+ * SURVEY 8(f) row 2 -- the surface glue around the energy in every iteration
+ * (reference geometry/tetmesh_geometry.py:27-66) and the one-off boundary extraction
+ * (geometry/mesh_utils.py:5-35).  All kernels are per-vertex gathers over fixed lists: no atomics,
+ * bitwise repeatable.  float32 values, int32 indices, [k,3] arrays row-major and contiguous.
+ */
+typedef struct tsamd_surface tsamd_surface;
+
+/* get_surface_vf(elem) (mesh_utils.py:5-35), host only: boundary triangles (faces of exactly one tet) ordered
+ * by their sorted vertex triple, oriented like the tet-local pattern they come from, vertex ids compacted to
+ * their rank in `surface_vid` (ascending tet-vertex ids).  Call once with surface_vid = faces = NULL to get the
+ * sizes, then with buffers of *n_surface_vertices and 3 * *n_faces entries (capacities passed in the counters). */
+int tsamd_extract_surface(const int32_t *tets, int64_t n_tets, int64_t n_vertices, int32_t *surface_vid,
+                          int64_t *n_surface_vertices, int32_t *faces, int64_t *n_faces);
+
+/* Device copy of the surface topology: surface_vid[ns] (TetMeshGeometry.surface_vid, tetmesh_geometry.py:146),
+ * faces[nf,3] indexing surface vertices (surface_fid, :148).  Host pointers; device < 0 = current device. */
+int tsamd_surface_create(const int32_t *surface_vid, int64_t n_surface_vertices, const int32_t *faces, int64_t n_faces,
+                         int64_t n_tet_vertices, int device, tsamd_surface **out);
+void tsamd_surface_destroy(tsamd_surface *s);
+
+/* v_pos = tet_v[surface_vid]  (tetmesh_geometry.py:33) and its adjoint: grad_tet_v[n_tet_vertices,3] is
+ * overwritten (zero, then the rows of grad_v_pos scattered; accumulated if surface_vid has duplicates). */
+int tsamd_surface_positions(const tsamd_surface *s, const float *tet_v_dev, void *stream, float *v_pos_dev);
+int tsamd_surface_positions_backward(const tsamd_surface *s, const float *grad_v_pos_dev, void *stream,
+                                     float *grad_tet_v_dev);
+
+/* _compute_vertex_normal() (tetmesh_geometry.py:39-66): face normals (v1-v0)x(v2-v0) summed per vertex,
+ * |n|^2 <= 1e-20 -> (0,0,1), n / max(|n|, 1e-12).  raw_dev (optional, [ns,3]) receives the unnormalised sums,
+ * which the backward needs.  Backward: grad_v_pos = (d v_nrm / d v_pos)^T grad_nrm; workspace: 12 * ns bytes. */
+int tsamd_vertex_normals(const tsamd_surface *s, const float *v_pos_dev, void *stream, float *v_nrm_dev, float *raw_dev);
+int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev, const float *raw_dev,
+                                  const float *grad_nrm_dev, void *workspace_dev, void *stream, float *grad_v_pos_dev);
+
 #ifdef __cplusplus
 }
 #endif

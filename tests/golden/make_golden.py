@@ -14,6 +14,8 @@ exists on the GPU box, hence the outputs are committed:
   (b) a full kuhn_ball(2).  Pins the oracle's `G` (oracle/tet_energy_oracle.py).
 * adam_uniform_golden.npz -- six steps of the REFERENCE optimiser class (utils/optimizer.py:4-89) in
   float64, with and without grad_limit: pins oracle/adam_uniform_oracle.py.
+* surface_golden.npz -- the reference's surface extraction, surface gather and vertex normals (+ autograd
+  gradient), see surface_golden() below: pins oracle/surface_oracle.py.
 * aveg_mesh.npz -- a.veg converted to the extension's input layout
   (float32 [n,3], int32 [m,4], 0-based): the "real TetWild-quality mesh"
   fixture of SURVEY.md 8(d).
@@ -83,7 +85,60 @@ def main():
     for k in ("plain_p0", "limited_p0"):
         out.pop(k)
     np.savez_compressed(os.path.join(HERE, "adam_uniform_golden.npz"), **out)
+    surface_golden(mu)
     print("wrote", os.listdir(HERE))
+
+
+def surface_golden(mu):
+    """surface_golden.npz -- the REFERENCE get_surface_vf (geometry/mesh_utils.py:5-35) on a.veg and a Kuhn
+    ball, and the REFERENCE TetMeshGeometryForwardData (geometry/tetmesh_geometry.py:27-66: surface gather +
+    _compute_vertex_normal) with its torch-autograd gradient, float64 on the CPU.  The module only imports with
+    its absent dependencies stubbed (trimesh, xatlas, omegaconf: never called here); pypgo / tet_spheres
+    resolve to this repository's stand-ins, which the class under test does not touch either."""
+    import types
+    import warnings
+    import torch
+    for name, attrs in {"trimesh": {}, "xatlas": {}, "omegaconf": {"OmegaConf": object, "open_dict": object, "DictConfig": dict}}.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    sys.path.insert(0, REF)
+    pkg = types.ModuleType("geometry")
+    pkg.__path__ = [f"{REF}/geometry"]
+    sys.modules["geometry"] = pkg
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        tg = importlib.import_module("geometry.tetmesh_geometry")
+    warnings.filterwarnings("ignore", message="Using torch.cross without specifying the dim")
+
+    out = {}
+    v, t = scenes.read_veg(f"{REF}/tssplat_ext/a.veg")
+    kv, kt = scenes.kuhn_ball(4)
+    for tag, verts, tets in (("aveg", v, t), ("kuhn4", kv, kt)):
+        vid, faces = mu.get_surface_vf(tets.astype(np.int64))
+        out[f"{tag}_vid"], out[f"{tag}_faces"] = vid.astype(np.int32), faces.astype(np.int32)
+        rng = np.random.default_rng(5)
+        x = verts.astype(np.float32).astype(np.float64) + 0.03 * rng.standard_normal(verts.shape)
+        if tag == "kuhn4":   # a degenerate fan: collapse every face around one surface vertex -> zero normal -> (0,0,1)
+            sv = int(vid[7])
+            ring = np.unique(vid[faces[(faces == 7).any(axis=1)]])
+            x[ring] = x[sv]
+        tet_v = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        data = tg.TetMeshGeometryForwardData(tet_v, torch.from_numpy(tets.astype(np.int64)), torch.from_numpy(vid.astype(np.int64)),
+                                             torch.from_numpy(faces.astype(np.int64)))
+        nrm = data._compute_vertex_normal()
+        w_n = torch.tensor(rng.standard_normal(tuple(nrm.shape)))
+        w_p = torch.tensor(rng.standard_normal(tuple(nrm.shape)))
+        loss = (nrm * w_n).sum() + (data.v_pos * w_p).sum()
+        loss.backward()
+        out[f"{tag}_x"] = x
+        out[f"{tag}_v_pos"] = data.v_pos.detach().numpy()
+        out[f"{tag}_nrm"] = nrm.detach().numpy()
+        out[f"{tag}_w_n"], out[f"{tag}_w_p"] = w_n.numpy(), w_p.numpy()
+        out[f"{tag}_grad_tet_v"] = tet_v.grad.numpy()
+    out["kuhn4_tets"] = kt.astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "surface_golden.npz"), **out)
 
 
 if __name__ == "__main__":

@@ -103,6 +103,18 @@ def test_real_mesh_aveg(ext, aveg):
         _assert_parity(ext, ts, sc.rest, sc.tets, x, 6e-5, 2e-4, order, label=f"a.veg x3 s={sigma} p={order}")
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_unstructured_delaunay(ext, seed):
+    """Random Delaunay balls (sliver-filtered): irregular valence, tets with 1-4 neighbours, multi-tile."""
+    from tssplat_amd import scenes
+    sc = scenes.make_scene("delaunay3000", 6, seed=seed)
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    assert ts.plan_info()["n_tiles"] > 6
+    for sigma, order in ((0.02, 2), (0.3, 4)):
+        x = scenes.deform(sc, sigma, seed=seed + 10)
+        _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / 6, 2e-4, order, label=f"delaunay seed={seed} s={sigma} o={order}")
+
+
 def test_cone_hub_vertex(ext):
     """One vertex of valence 1280: LDS-atomic contention must not change the result."""
     from tssplat_amd import scenes

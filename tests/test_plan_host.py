@@ -43,13 +43,16 @@ def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
     ("kuhn12", 1, dict(debug_shuffle=True)),
     ("cone", 2, {}),                                   # hub vertex of valence 1280
     ("cone", 1, dict(lds_budget_bytes=30000)),
+    ("delaunay700", 2, {}),                            # unstructured: irregular valence, holes, no index locality
+    ("delaunay2500", 1, dict(lds_budget_bytes=50000, max_threads=512)),
 ])
 def test_plan_replays_to_oracle(ext, kind, S, kw):
     sc = scenes.make_scene(kind, S)
     ts = _check(ext, sc, kw, cases=((0.02, 2, 1.0), (0.3, 4, 0.5)))
     info = ts.plan_info()
     assert info["n_tets"] == sc.n_tets and info["n_vertices"] == sc.n_vertices
-    assert info["n_components"] == S
+    # sliver removal can split a Delaunay ball into several face-connected pieces
+    assert info["n_components"] == S or (kind.startswith("delaunay") and info["n_components"] >= S)
     assert info["total_slots"] >= sc.n_tets
     assert info["block_threads"] % 64 == 0 and 64 <= info["block_threads"] <= 1024
     assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 81920)

@@ -89,6 +89,15 @@ SIGNATURES = {
                                         C.c_float, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
     "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    # surface glue
+    "tsamd_extract_surface": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+                                      C.POINTER(C.c_int64)]),
+    "tsamd_surface_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]),
+    "tsamd_surface_destroy": (None, [C.c_void_p]),
+    "tsamd_surface_positions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsamd_surface_positions_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsamd_vertex_normals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsamd_vertex_normals_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#include "capi_common.h"
 #include "kernels.h"
 #include "plan.h"
 
@@ -32,34 +33,13 @@ int fail(int code, const std::string &msg)
     return code;
 }
 
-#define TSAMD_HIP(call)                                                                             \
-    do {                                                                                            \
-        hipError_t e__ = (call);                                                                    \
-        if (e__ != hipSuccess)                                                                      \
-            return fail(TSAMD_ERR_HIP, std::string(#call) + " failed: " + hipGetErrorString(e__)); \
-    } while (0)
-
-struct DeviceGuard {
-    int prev = -1;
-    bool active = false;
-    hipError_t enter(int dev)
-    {
-        hipError_t e = hipGetDevice(&prev);
-        if (e != hipSuccess) return e;
-        if (prev != dev) {
-            e = hipSetDevice(dev);
-            if (e != hipSuccess) return e;
-            active = true;
-        }
-        return hipSuccess;
-    }
-    ~DeviceGuard()
-    {
-        if (active) (void)hipSetDevice(prev);
-    }
-};
-
 }  // namespace
+
+namespace tsamd {
+int capi_fail(int code, const std::string &msg) { return fail(code, msg); }
+}  // namespace tsamd
+
+using tsamd::DeviceGuard;
 
 struct tsamd_handle {
     tsamd::Plan plan;

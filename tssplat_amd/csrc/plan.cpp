@@ -62,6 +62,8 @@ struct BucketFace {
     uint32_t b, c, slot;  // the smallest vertex is the bucket id; slot = 4*tet + opposite local vertex
 };
 
+}  // namespace
+
 // nbr[4e+k] = tet across the face of e opposite local vertex k, -1 on the boundary.
 int build_adjacency(const int32_t *tets, int64_t n, int64_t m, std::vector<int32_t> &nbr, int nthreads,
                     std::string &err)
@@ -116,6 +118,8 @@ int build_adjacency(const int32_t *tets, int64_t n, int64_t m, std::vector<int32
     }
     return OK;
 }
+
+namespace {
 
 // per-worker scratch with O(1) reset through stamps
 struct Scratch {

@@ -96,6 +96,11 @@ struct Plan {
 int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt,
                Plan &plan, std::string &err);
 
+// nbr[4e+k] = tet across the face of e opposite local vertex k, -1 on the boundary; a face shared by more
+// than two tets is an error.  nthreads <= 1 runs serially.
+int build_adjacency(const int32_t *tets, int64_t n, int64_t m, std::vector<int32_t> &nbr, int nthreads,
+                    std::string &err);
+
 // Minimal Vega .veg reader (*VERTICES / *ELEMENTS TET), 0-based output.
 int read_veg(const char *path, std::vector<float> &rest, std::vector<int32_t> &tets, std::string &err);
 

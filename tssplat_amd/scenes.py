@@ -152,6 +152,28 @@ def cone_sphere(surface_v: np.ndarray, surface_f: np.ndarray) -> tuple[np.ndarra
     return verts, tets
 
 
+def delaunay_ball(n_points: int, seed: int = 0, min_quality: float = 0.08) -> tuple[np.ndarray, np.ndarray]:
+    """Unstructured fixture: Delaunay tetrahedralisation of random points in the unit ball, slivers removed.
+
+    Unlike the Kuhn lattice this has irregular valence (3 .. ~40 tets per vertex), interior holes where
+    slivers were dropped (tets with fewer than four neighbours anywhere in the mesh) and no index
+    locality.  Quality = 6 sqrt(2) V / l_rms^3 (1 for a regular tet); dropping tets keeps the mesh
+    face-manifold.  Needs scipy (tests / tools only).
+    """
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal((n_points, 3))
+    p *= (rng.uniform(0, 1, size=(n_points, 1)) ** (1 / 3)) / np.linalg.norm(p, axis=1, keepdims=True)
+    tets = Delaunay(p).simplices.astype(np.int32)
+    tets = _orient_positive(p, tets)
+    q = p[tets]
+    vol = np.einsum("ij,ij->i", np.cross(q[:, 1] - q[:, 0], q[:, 2] - q[:, 0]), q[:, 3] - q[:, 0]) / 6.0
+    edges = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    l2 = sum(((q[:, a] - q[:, b]) ** 2).sum(axis=1) for a, b in edges) / 6.0
+    quality = 6.0 * np.sqrt(2.0) * vol / l2 ** 1.5
+    return p, np.ascontiguousarray(tets[quality >= min_quality])
+
+
 def replicate_spheres(verts: np.ndarray, tets: np.ndarray, n_spheres: int,
                       seed: int = 0) -> TetScene:
     """Stack ``n_spheres`` scaled/translated copies of one template tet mesh.
@@ -180,11 +202,13 @@ def replicate_spheres(verts: np.ndarray, tets: np.ndarray, n_spheres: int,
 
 def make_scene(kind: str, n_spheres: int, seed: int = 0) -> TetScene:
     """Named workloads: ``kuhn8`` (3 072 tets/sphere), ``kuhn19`` (41 154),
-    ``kuhnK`` for any K, ``cone`` (icosphere coned to its centre)."""
+    ``kuhnK`` for any K, ``cone`` (icosphere coned to its centre), ``delaunayN`` (N random points)."""
     if kind.startswith("kuhn"):
         v, t = kuhn_ball(int(kind[4:]))
     elif kind == "cone":
         v, t = cone_sphere(*icosphere_surface(3))
+    elif kind.startswith("delaunay"):
+        v, t = delaunay_ball(int(kind[8:]), seed=seed)
     else:
         raise ValueError(f"unknown scene kind {kind!r}")
     return replicate_spheres(v, t, n_spheres, seed=seed)
