@@ -186,7 +186,8 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
 // SIMD): <1024, 4> gives 128 VGPRs and one workgroup per CU, <768, 6> 80 VGPRs and two.
 // Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
-// prefetch, and touching a successor tile's planes into L2, were both measured slower: DESIGN.md section 8.)
+// prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
+// within noise: DESIGN.md section 4.)
 template <bool WITH_GRAD, int SPT>
 __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
 {
@@ -216,23 +217,31 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     const bool active = tid < nq;
     const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);  // 13 planes of s_pad dwords
     // (non-temporal loads of the planes were measured: tile kernel +1.4 %, finish kernel -4 %, net slower)
-    auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * tid); };
-    auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * tid); };
+    // lanes beyond the tile read lane 0's entries (and never use them): with every load unconditional the stream
+    // is straight-line code and the compiler can count its waits (vmcnt(13)) instead of draining to vmcnt(0)
+    const int lt = active ? tid : 0;
+    auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * lt); };
+    auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * lt); };
     STAMP(0);
+    // The position gather is a chain of two dependent loads (vertex id, then x).  vmcnt retires in order, so the
+    // id load goes out FIRST: the wait for it then does not include the 13 plane loads, and the x loads travel
+    // together with the planes instead of behind them.
+    int32_t gv0 = g_gvid[td.vert_off + (tid < td.n_verts ? tid : 0)];
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
-    VU q_lv01 = 0, q_lv23 = 0, q_nb01 = 0, q_nb23 = 0;
+    VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     VF dm[9];
-    if (active) {
-        q_lv01 = plane_u(0);
-        q_lv23 = plane_u(1);
-        q_nb01 = plane_u(2);
-        q_nb23 = plane_u(3);
 #pragma unroll
-        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
-    }
+    for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
-    // stage this tile's vertex positions (behind the plane loads just issued)
-    for (int v = tid; v < td.n_verts; v += nthr) {
+    // stage this tile's vertex positions; the fence keeps the compiler from waiting for the vertex id (and so for
+    // nothing else: vmcnt(13)) before the plane loads above have been issued
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(gv0));  // (address arithmetic on the id would otherwise be hoisted up to its load)
+    if (tid < td.n_verts) {
+        const size_t gv = size_t(gv0) * 3;
+        reinterpret_cast<float4 *>(xs)[tid] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+    }
+    for (int v = tid + nthr; v < td.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
         const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
         reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
     }
