@@ -526,57 +526,70 @@ struct FinishArgs {
     double *terms;
 };
 
-// Per-tile energy partials -> E = c1 E_s + c2 E_b (tet_spheres_cuda.cu:191), one workgroup, fixed order
-// (bitwise repeatable).  Each thread owns tiles tid, tid + 1024, ... and issues its loads in batches of
-// eight before summing: a plain dependent loop costs one HBM latency per tile (60 us for 19 k tiles).
-__global__ __launch_bounds__(1024) void energy_reduce_kernel(const FinishArgs a)
+// Per-tile energy partials -> E = c1 E_s + c2 E_b (tet_spheres_cuda.cu:191), one workgroup of T threads, fixed
+// order (bitwise repeatable).  Each thread owns tiles tid, tid + T, ... and issues its loads in batches of eight
+// before summing: a plain dependent loop costs one HBM latency per tile (60 us for 19 k tiles).
+template <int T>
+__device__ __forceinline__ void energy_reduce(const FinishArgs &a, double *red)
 {
-    __shared__ double red[2 * 1024];
     const int tid = threadIdx.x;
     const double2 *part = reinterpret_cast<const double2 *>(a.partials);
     double s = 0.0, b = 0.0;
     int64_t t = tid;
-    for (; t + 7 * 1024 < a.n_tiles; t += 8 * 1024) {
+    for (; t + 7 * T < a.n_tiles; t += 8 * T) {
         double2 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = part[t + u * 1024];
+        for (int u = 0; u < 8; ++u) v[u] = part[t + u * T];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             s += v[u].x;
             b += v[u].y;
         }
     }
-    for (; t < a.n_tiles; t += 1024) {
+    for (; t < a.n_tiles; t += T) {
         const double2 v = part[t];
         s += v.x;
         b += v.y;
     }
     red[tid] = s;
-    red[1024 + tid] = b;
+    red[T + tid] = b;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
+    for (int off = T / 2; off > 0; off >>= 1) {
         if (tid < off) {
             red[tid] += red[tid + off];
-            red[1024 + tid] += red[1024 + tid + off];
+            red[T + tid] += red[T + tid + off];
         }
         __syncthreads();
     }
     if (tid == 0) {
         a.terms[0] = red[0];
-        a.terms[1] = red[1024];
-        a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[1024]);
+        a.terms[1] = red[T];
+        a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[T]);
     }
 }
 
-// Vertices touched by several tiles: sum their staged partial gradients in plan order (deterministic).
+// Forward-only evaluations: just the energy.
+__global__ __launch_bounds__(1024) void energy_reduce_kernel(const FinishArgs a)
+{
+    __shared__ double red[2 * 1024];
+    energy_reduce<1024>(a, red);
+}
+
+// Workgroup 0 reduces the energy partials (when asked to) while the others sum, for every vertex touched by
+// several tiles, its staged partial gradients in plan order (deterministic): one launch, and the 8 us of the
+// single-workgroup reduction hide behind the vertex work.
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
 {
+    __shared__ double red[2 * 256];
     const int tid = threadIdx.x;
-    if (!a.grad) return;
+    if (blockIdx.x == 0) {
+        if (a.energy) energy_reduce<256>(a, red);
+        return;
+    }
     const float gscale = a.grad_out ? *a.grad_out : 1.f;
     // one thread per shared vertex (measured faster than one thread per output float: 0.065 vs 0.093 ms)
-    const int64_t stride = int64_t(gridDim.x) * 256;
-    for (int64_t k = int64_t(blockIdx.x) * 256 + tid; k < a.n_finish; k += stride) {
+    const int64_t stride = int64_t(gridDim.x - 1) * 256;
+    for (int64_t k = int64_t(blockIdx.x - 1) * 256 + tid; k < a.n_finish; k += stride) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
         for (int32_t e = a.fin_off[k]; e < a.fin_off[k + 1]; ++e) {  // consecutive rows, tile order
             const float *r = a.stage + size_t(e) * 3;
@@ -809,14 +822,13 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     f.c2 = e.c2;
     f.energy = e.energy;
     f.terms = e.terms;
-    if (f.energy) {
-        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
-        hipError_t err = hipGetLastError();
-        if (err != hipSuccess) return err;
-    }
     if (f.n_finish > 0) {
         // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
-        hipLaunchKernelGGL(finish_kernel, dim3(unsigned(grid_for(f.n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
+        hipLaunchKernelGGL(finish_kernel, dim3(1u + unsigned(grid_for(f.n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
+        return hipGetLastError();
+    }
+    if (f.energy) {
+        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
         return hipGetLastError();
     }
     return hipSuccess;
