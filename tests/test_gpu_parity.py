@@ -50,8 +50,12 @@ def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0,
     e_gpu, g_gpu = _eval_gpu(ext, ts, x_np, c1, c2, order, go)
     err_e = abs(e_gpu - E)
     err_g = float(np.linalg.norm(g_gpu - g))
-    print(f"[{label}] E={E:.6e} gpu={e_gpu:.6e} err={err_e:.2e} tol={tol_e:.2e} band={band_e:.2e} | "
-          f"|g|={np.linalg.norm(g):.4e} err={err_g:.2e} tol={abs(go) * tol_g:.2e} band={band_g:.2e}")
+    line = (f"[{label}] E={E:.6e} gpu={e_gpu:.6e} err={err_e:.2e} tol={tol_e:.2e} band={band_e:.2e} | "
+            f"|g|={np.linalg.norm(g):.4e} err={err_g:.2e} tol={abs(go) * tol_g:.2e} band={band_g:.2e}")
+    print(line)
+    if os.environ.get("TSSPLAT_AMD_PARITY_REPORT"):      # profiles/r01_parity.txt is made this way
+        with open(os.environ["TSSPLAT_AMD_PARITY_REPORT"], "a") as fh:
+            fh.write(line + "\n")
     assert np.isfinite(e_gpu) and np.isfinite(g_gpu).all()
     assert err_e <= tol_e, f"{label}: energy error {err_e:.3e} > factored tolerance {tol_e:.3e}"
     assert err_g <= abs(go) * tol_g, f"{label}: gradient error {err_g:.3e} > factored tolerance {abs(go) * tol_g:.3e}"
