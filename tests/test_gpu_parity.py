@@ -203,12 +203,13 @@ def test_autograd_surface_and_cache(ext):
     g_cpu_go = ext_backward_cpu_go(mod, x, c1, c2)
     assert torch.allclose(g_cpu_go, g_cached, rtol=1e-5, atol=1e-6 * float(g_cached.abs().max()))
     # reference CPU-energy convention on request
-    os.environ["TSSPLAT_AMD_CPU_ENERGY"] = "1"
+    from tssplat_amd import tet_spheres_ext as _ext
+    _ext.CPU_ENERGY = True
     try:
         e_cpu = mod(x, 1200, c1, c2)
         assert not e_cpu.is_cuda and e_cpu.dim() == 0
     finally:
-        os.environ.pop("TSSPLAT_AMD_CPU_ENERGY")
+        _ext.CPU_ENERGY = False
 
 
 def ext_backward_cpu_go(mod, x, c1, c2):

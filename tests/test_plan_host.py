@@ -161,7 +161,8 @@ def test_import_path_shim_and_operator_surface(capsys):
         assert hasattr(shim, name)
     from tssplat_amd.energies import SmoothnessBarrierEnergy, SmoothnessBarrierFunc
     import inspect
-    assert list(inspect.signature(SmoothnessBarrierFunc.forward).parameters) == ["x_cur", "tet_sp", "c1", "c2", "order"]
+    # same apply(x_cur, tet_sp, c1, c2, order) call as smooth_barrier.py:9-31 (ctx-first spelling: see the class docstring)
+    assert list(inspect.signature(SmoothnessBarrierFunc.forward).parameters) == ["ctx", "x_cur", "tet_sp", "c1", "c2", "order"]
     assert list(inspect.signature(SmoothnessBarrierEnergy.forward).parameters) == ["self", "x", "it", "c1", "c2"]
     rx = real.random_x(type("T", (), {"n": 7})())
     assert tuple(rx.shape) == (7, 3)

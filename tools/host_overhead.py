@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Host-side cost of one energy evaluation on a small scene (64 x kuhn8: ~12 us of GPU work), layer by layer:
+direct operator calls, the autograd Function, the nn.Module.  Steady state on the MI355X box: 16 us direct,
+~47 us through autograd (of which ~25 us is an empty autograd.Function round trip).  Note the first ~2000
+autograd steps of a process run at about twice that (runtime warm-up), which is what short benchmarks see.
+
+    python tools/host_overhead.py
+"""
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+from tssplat_amd import scenes, _capi, tet_spheres_ext as T
+from tssplat_amd.energies import SmoothnessBarrierEnergy, SmoothnessBarrierFunc
+class F: smooth_eng_coeff=2e-4/64; barrier_coeff=2e-4; increase_order_iter=1000
+sc = scenes.make_scene("kuhn8", 64)
+en = SmoothnessBarrierEnergy(sc.rest, sc.tets, F)
+x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, 0.02)).cuda())
+ts = en.tet_sp
+one = torch.ones((), device="cuda")
+pc = time.perf_counter
+def run(name, fn, N=2000):
+    for i in range(100): fn(i)
+    torch.cuda.synchronize()
+    t = pc()
+    for i in range(N): fn(i)
+    h = pc() - t
+    torch.cuda.synchronize()
+    print(f"{name:52s} host {1e6 * h / N:6.1f} us  total {1e6 * (pc() - t) / N:6.1f} us")
+run("ext.forward(x requires_grad) + ext.backward direct", lambda i: (T.forward(x, ts, 1e-4, 2e-4, 2), T.backward(one, x, ts, 1e-4, 2e-4, 2)))
+run("ext.forward only (fused, cache overwritten)", lambda i: T.forward(x, ts, 1e-4, 2e-4, 2))
+def f_apply(i):
+    return SmoothnessBarrierFunc.apply(x, ts, 1e-4, 2e-4, 2)
+run("Func.apply forward only (graph built, dropped)", f_apply)
+def f_full(i):
+    x.grad = None
+    SmoothnessBarrierFunc.apply(x, ts, 1e-4, 2e-4, 2).backward()
+run("Func.apply + backward()", f_full)
+def f_full_keepgrad(i):
+    SmoothnessBarrierFunc.apply(x, ts, 1e-4, 2e-4, 2).backward()
+x.grad = None
+run("Func.apply + backward(), grad accumulates", f_full_keepgrad)
+g1 = torch.ones((), device="cuda")
+def f_full_g(i):
+    x.grad = None
+    SmoothnessBarrierFunc.apply(x, ts, 1e-4, 2e-4, 2).backward(g1)
+run("Func.apply + backward(given ones)", f_full_g)
+def f_mod(i):
+    x.grad = None
+    en(x, i, 1e-4, 2e-4).backward()
+run("module call + backward()", f_mod)

@@ -21,8 +21,8 @@ Deliberate differences from the reference (all listed in DESIGN.md):
 
 * ``forward`` returns the energy on ``input``'s device and never blocks the host
   (the reference returns a CPU 0-dim tensor after two blocking reads,
-  tet_spheres_cuda.cu:154,185,194).  Set ``TSSPLAT_AMD_CPU_ENERGY=1`` for the
-  reference's CPU return.  ``backward`` accepts ``gradH`` on either device and
+  tet_spheres_cuda.cu:154,185,194).  Set ``TSSPLAT_AMD_CPU_ENERGY=1`` before import
+  (or ``tet_spheres_ext.CPU_ENERGY = True``) for the reference's CPU return.  ``backward`` accepts ``gradH`` on either device and
   applies it on the GPU without ``.item()`` (contrast .cu:257).
 * when ``input.requires_grad`` the forward call evaluates energy *and*
   gradient in one fused pass and keeps the unscaled gradient on the
@@ -37,6 +37,7 @@ Deliberate differences from the reference (all listed in DESIGN.md):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -49,17 +50,27 @@ from . import _capi
 __all__ = ["TetSpheres", "forward", "backward", "random_x", "grad_limit"]
 
 _lib = _capi.load()          # fail loudly at import if the HIP library is absent
+CPU_ENERGY = os.environ.get("TSSPLAT_AMD_CPU_ENERGY", "0") == "1"   # read once: os.environ lookups are slow
 print("initializing")         # tet_spheres.cpp:19 prints this at module import
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_ptr(device: torch.device) -> int:
+    """hipStream_t of torch's current stream on `device` (the raw query is ~10x cheaper than building a
+    torch.cuda.Stream object on every call)."""
+    if _raw_stream is not None and device.index is not None:
+        return int(_raw_stream(device.index))
     return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+_NULL_CTX = contextlib.nullcontext()
 
 
 def _device_ctx(device: torch.device):
     """Handle-less entry points (scale, grad_limit) launch on the current device: switch only if needed."""
-    import contextlib
-    return contextlib.nullcontext() if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+    return _NULL_CTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
 class TetSpheres:
@@ -172,7 +183,8 @@ def _check_input(x: torch.Tensor, ts: TetSpheres) -> torch.Tensor:
 
 
 def _cache_key(x: torch.Tensor, c1: float, c2: float, order: int):
-    return (x.data_ptr(), x._version, tuple(x.shape), float(np.float32(c1)), float(np.float32(c2)), int(order))
+    # (a miss only costs a recomputation, so the coefficients are compared as given, not after fp32 narrowing)
+    return (x.data_ptr(), x._version, x.shape, float(c1), float(c2), int(order))
 
 
 def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, order: int) -> torch.Tensor:
@@ -189,7 +201,7 @@ def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, orde
         tet_sph._cache = (_cache_key(input, c1, c2, order), g)
     else:
         _capi.check(_lib.tsamd_forward(h, x.data_ptr(), c1, c2, int(order), stream, energy.data_ptr()))
-    if os.environ.get("TSSPLAT_AMD_CPU_ENERGY", "0") == "1":
+    if CPU_ENERGY:
         return energy.cpu()                             # the reference's convention, .cu:194
     return energy
 
@@ -197,29 +209,32 @@ def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, orde
 def backward(gradH: torch.Tensor, input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float,
              order: int) -> torch.Tensor:
     """``gradH * dE/dx`` with the shape/dtype/device of ``input`` (tet_spheres_cuda.cu:197-263)."""
-    h = tet_sph._handle()
-    x = _check_input(input, tet_sph)
-    if isinstance(gradH, torch.Tensor) and gradH.device == x.device and gradH.dtype == torch.float32 \
+    cached = tet_sph._cache
+    tet_sph._cache = None
+    hit = cached is not None and cached[0] == _cache_key(input, c1, c2, order)
+    # a hit means `input` is the very tensor the fused forward validated a moment ago
+    x = input if hit and input.is_contiguous() else _check_input(input, tet_sph)
+    dev = x.device
+    if isinstance(gradH, torch.Tensor) and gradH.device == dev and gradH.dtype == torch.float32 \
             and gradH.numel() == 1:
         go = gradH                                      # the usual case: autograd hands over a device scalar
     else:
         if not isinstance(gradH, torch.Tensor):
             gradH = torch.tensor(float(gradH), dtype=torch.float32)
-        go = gradH.detach().to(device=x.device, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
-    stream = _stream_ptr(x.device)
-    cached = tet_sph._cache
-    tet_sph._cache = None
-    if cached is not None and cached[0] == _cache_key(input, c1, c2, order):
+        go = gradH.detach().to(device=dev, dtype=torch.float32, non_blocking=True).reshape(-1)[:1].contiguous()
+    stream = _stream_ptr(dev)
+    if hit:
         # the cached gradient is ours: scale it in place (the kernel returns at once when gradH == 1,
         # the usual case for a loss term, so no second pass over the gradient) and hand it over
         out = cached[1]
-        with _device_ctx(x.device):
+        with _device_ctx(dev):
             _capi.check(_lib.tsamd_scale(out.data_ptr(), go.data_ptr(), out.data_ptr(), out.numel(), stream))
     else:
         out = torch.empty_like(x)
-        _capi.check(_lib.tsamd_backward(h, x.data_ptr(), go.data_ptr(), c1, c2, int(order), stream,
+        _capi.check(_lib.tsamd_backward(tet_sph._handle(), x.data_ptr(), go.data_ptr(), c1, c2, int(order), stream,
                                         out.data_ptr()))
-    return out.view(input.shape)
+    # (not a view when the shapes already agree: autograd can then take the buffer instead of cloning it)
+    return out if out.shape == input.shape else out.view(input.shape)
 
 
 def random_x(tet_sph: TetSpheres) -> torch.Tensor:
