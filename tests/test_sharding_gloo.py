@@ -87,7 +87,11 @@ def _worker(rank, world, port, out):
         c1, c2 = mod.coeff_scheduler(0)
         e = mod(xl, 0, c1, c2)
         (2.0 * e).backward()
-        out[rank] = (float(e), mod.sphere_range, (lo, hi), xl.grad.numpy().copy())
+        # replicated parameter: same energy, full gradient on every rank (one all-gather in backward)
+        xf = torch.from_numpy(x).requires_grad_(True)
+        ef = mod.forward_replicated(xf, 0, c1, c2)
+        (2.0 * ef).backward()
+        out[rank] = (float(e), mod.sphere_range, (lo, hi), xl.grad.numpy().copy(), float(ef), xf.grad.numpy().copy())
     finally:
         dist.destroy_process_group()
 
@@ -117,7 +121,8 @@ def test_two_ranks_match_unsharded_oracle():
     E, _, _, g = O.energy_and_grad(x, cache, _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2, grad_output=2.0)
     covered = np.zeros(rest.shape[0], dtype=bool)
     for rank in range(world):
-        e, srange, (lo, hi), grad = out[rank]
+        e, srange, (lo, hi), grad, ef, grad_full = out[rank]
+        assert abs(ef - E) <= 2e-6 * abs(E) and np.abs(grad_full - g).max() <= 1e-5 * np.abs(g).max()
         assert abs(e - E) <= 2e-6 * abs(E)                 # every rank sees the job-wide energy
         assert np.abs(grad - g[lo:hi]).max() <= 1e-5 * np.abs(g).max()   # and only its own gradient slice
         assert not covered[lo:hi].any()
@@ -137,6 +142,9 @@ def test_single_process_is_identity():
     E, _, _, g = O.energy_and_grad(x, O.prepare(rest, tets), _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2)
     assert abs(float(e) - E) <= 2e-6 * abs(E)
     assert np.abs(xl.grad.numpy() - g).max() <= 1e-5 * np.abs(g).max()
+    xf = torch.from_numpy(x).requires_grad_(True)
+    mod.forward_replicated(xf, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff).backward()
+    assert np.abs(xf.grad.numpy() - g).max() <= 1e-5 * np.abs(g).max()
 
 
 def test_rejects_spheres_that_share_vertices():

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy"]
+__all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy", "slice_replicated"]
 
 
 def partition_spheres(tets_per_sphere: Sequence[int], world_size: int) -> list[tuple[int, int]]:
@@ -55,6 +55,46 @@ class _AddGlobal(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         return grad_out, None
+
+
+class _SliceReplicated(torch.autograd.Function):
+    """``x_full[lo:hi]`` whose backward returns the FULL gradient on every rank: each rank contributes the
+    gradient of its own vertex range and the ranges are exchanged with one all-gather (uneven sizes, RCCL
+    all-gather over xGMI on a GPU node).  For trainers that keep ``tet_v`` replicated on all ranks
+    (the reference trainer unchanged, e.g. with view-parallel rendering)."""
+
+    @staticmethod
+    def forward(ctx, x_full, ranges, rank, group):
+        ctx.ranges, ctx.rank, ctx.group, ctx.shape = ranges, rank, group, x_full.shape
+        lo, hi = ranges[rank]
+        return x_full[lo:hi].contiguous()
+
+    @staticmethod
+    def backward(ctx, grad_local):
+        rows = [hi - lo for lo, hi in ctx.ranges]
+        make = torch.empty if sum(rows) == ctx.shape[0] else torch.zeros    # rows no rank owns get a zero gradient
+        full = make(ctx.shape, dtype=grad_local.dtype, device=grad_local.device)
+        lo, hi = ctx.ranges[ctx.rank]
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(ctx.group) == 1:
+            full[lo:hi] = grad_local
+        elif len(set(rows)) == 1 and sum(rows) == ctx.shape[0]:
+            dist.all_gather_into_tensor(full, grad_local.contiguous(), group=ctx.group)   # lands in place
+        else:
+            # uneven ranges: gather equal-sized (padded) blocks, then copy each rank's rows to their place
+            # (all_gather of uneven tensor lists is not available on every backend)
+            mx = max(rows)
+            block = torch.zeros((mx,) + tuple(ctx.shape[1:]), dtype=grad_local.dtype, device=grad_local.device)
+            block[: hi - lo] = grad_local
+            gathered = torch.empty((len(rows) * mx,) + tuple(ctx.shape[1:]), dtype=grad_local.dtype, device=grad_local.device)
+            dist.all_gather_into_tensor(gathered, block, group=ctx.group)
+            for r, (a, b) in enumerate(ctx.ranges):
+                full[a:b] = gathered[r * mx: r * mx + (b - a)]
+        return full, None, None, None
+
+
+def slice_replicated(x_full: torch.Tensor, vertex_ranges, rank: int, group=None) -> torch.Tensor:
+    """This rank's rows of a replicated ``[n, 3]`` tensor; its gradient comes back all-gathered to ``[n, 3]``."""
+    return _SliceReplicated.apply(x_full, [tuple(map(int, r)) for r in vertex_ranges], int(rank), group)
 
 
 def all_reduce_energy(local_energy: torch.Tensor, group=None, async_op: bool = False):
@@ -97,6 +137,7 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         lo, hi = self.ranges[self.rank]
         self.sphere_range = (lo, hi)
         self.vertex_range = (int(vo[lo]), int(vo[hi]))
+        self.vertex_ranges = [(int(vo[a]), int(vo[b])) for a, b in self.ranges]   # of every rank (slice_replicated)
         self.tet_range = (int(to[lo]), int(to[hi]))
         v = np.asarray(tet_v).reshape(-1, 3)[self.vertex_range[0]:self.vertex_range[1]]
         f = np.asarray(tet_f).reshape(-1, 4)[self.tet_range[0]:self.tet_range[1]] - self.vertex_range[0]
@@ -113,6 +154,11 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
             return self.local.coeff_scheduler(it)
         from .energies import SmoothnessBarrierEnergy
         return SmoothnessBarrierEnergy.coeff_scheduler(self, it)
+
+    def forward_replicated(self, x_full: torch.Tensor, it, c1, c2):
+        """Same energy from a ``tet_v`` replicated on every rank: evaluates this rank's spheres and hands
+        every rank the full ``[n, 3]`` gradient (one all-gather of the rank slices in backward)."""
+        return self.forward(slice_replicated(x_full, self.vertex_ranges, self.rank, self.group), it, c1, c2)
 
     def forward(self, x_local: torch.Tensor, it, c1, c2):
         if self.local is not None:
