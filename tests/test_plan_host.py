@@ -183,3 +183,37 @@ def test_coeff_schedule_matches_reference_formula():
         assert c1 == F.smooth_eng_coeff * mult and c2 == F.barrier_coeff * mult
     assert SmoothnessBarrierEnergy.coeff_scheduler(fake, 0) == (2e-4, 3e-4)
     assert abs(SmoothnessBarrierEnergy.coeff_scheduler(fake, 1200)[0] / 2e-4 - 16) < 1e-12
+
+
+# ---- randomised plans: any mesh, any tiling options -> the plan replays to the oracle or the build fails loudly ----
+from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(kind=st.sampled_from(["kuhn2", "kuhn4", "kuhn6", "delaunay150", "delaunay500", "cone"]),
+       spheres=st.integers(1, 3),
+       lds=st.sampled_from([0, 12000, 24000, 40960, 65536, 81920, 120000, 163840]),
+       threads=st.sampled_from([0, 64, 128, 256, 512, 768, 1024]),
+       spt=st.sampled_from([2, 4]),
+       balance=st.booleans(),
+       target=st.sampled_from([0, 50, 300, 1000]),
+       debug=st.integers(0, 3),
+       seed=st.integers(0, 3))
+def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, spt, balance, target, debug, seed):
+    from tssplat_amd import tet_spheres_ext as ext
+    sc = scenes.make_scene(kind, spheres, seed=seed)
+    kw = dict(lds_budget_bytes=lds, max_threads=threads, slots_per_thread=spt, balance_slots=balance,
+              target_owned=target, debug_shuffle=debug)
+    try:
+        ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, **kw)
+    except RuntimeError as e:      # an infeasible budget must say so, not produce a broken plan
+        assert re.search(r"LDS budget|cannot be tiled|exceeds|too (long|many)", str(e)), str(e)
+        return
+    info = ts.plan_info()
+    assert info["lds_bytes"] <= (lds or 81920) and info["block_threads"] <= (threads or 768)
+    assert info["slots_per_thread"] * info["block_threads"] >= info["max_slots"]
+    cache = O.prepare(sc.rest, sc.tets)
+    x = scenes.deform(sc, 0.2, seed=seed + 7)
+    E, Es, Eb, g = O.energy_and_grad(x, cache, 3e-5, 2e-4, 4, grad_output=0.7)
+    E2, Es2, Eb2, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 4, grad_output=0.7)
+    assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()
