@@ -327,3 +327,29 @@ def test_degenerate_inputs(ext):
     # poisoned output buffers must be fully overwritten by the non-cached backward as well
     g2 = ext.backward(torch.tensor(1.0), x.detach(), ts, 1.0, 1.0, 2)
     assert torch.allclose(g, g2, rtol=1e-6, atol=1e-7)
+
+
+def test_random_tiling_options_on_gpu(ext):
+    """Every kernel instantiation (2 or 4 tets per lane, one or two workgroups per CU, any block size) and
+    tiling option against the oracle on small mixed meshes -- a fixed pseudo-random sample of the option space."""
+    from tssplat_amd import scenes
+    rng = np.random.default_rng(2024)
+    kinds = ["kuhn4", "kuhn8", "delaunay400", "delaunay1500", "cone"]
+    ran = 0
+    for trial in range(16):
+        kind = kinds[trial % len(kinds)]
+        kw = dict(lds_budget_bytes=int(rng.choice([0, 24000, 40960, 65536, 81920, 120000, 163840])),
+                  max_threads=int(rng.choice([0, 128, 256, 512, 768, 1024])),
+                  slots_per_thread=int(rng.choice([2, 4])), balance_slots=bool(rng.integers(2)),
+                  target_owned=int(rng.choice([0, 200, 900])), debug_shuffle=int(rng.integers(4)))
+        sc = scenes.make_scene(kind, int(rng.integers(1, 4)), seed=trial)
+        try:
+            ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), **kw)
+        except RuntimeError as e:
+            assert "LDS budget" in str(e) or "tiled" in str(e), str(e)
+            continue
+        x = scenes.deform(sc, float(rng.choice([0.02, 0.3])), seed=trial + 50)
+        _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / sc.n_spheres, 2e-4, int(rng.choice([2, 4])),
+                       go=float(rng.choice([1.0, 0.25])), label=f"random#{trial} {kind} {kw}")
+        ran += 1
+    assert ran >= 10
