@@ -10,6 +10,8 @@
  *   tsamd_create            <- TetSpheres::TetSpheres(int nv, double*, int ntet, int*)   tet_spheres.cpp:119-126
  *                              + TetSpheres::init                                        tet_spheres.cpp:140-203
  *                              + the pybind array constructor                            tet_spheres.cpp:234-258
+ *   tsamd_create_with_operator <- the same, with the element Laplacian that the reference takes from libpgo
+ *                              (pgo_create_tet_biharmonic_gradient_matrix, tet_spheres.cpp:148) passed as data
  *   tsamd_create_from_veg   <- TetSpheres::TetSpheres(const std::string& filename)       tet_spheres.cpp:108-117
  *   tsamd_destroy           <- TetSpheres::~TetSpheres                                   tet_spheres.cpp:128-138
  *   tsamd_forward           <- tet_spheres_smooth_barrier          (forward)             tet_spheres_cuda.cu:118-195
@@ -77,7 +79,8 @@ typedef struct tsamd_plan_info {
     int64_t finish_vertices;     /* global vertices written by the finish kernel                    */
     int64_t device_bytes;        /* bytes of plan data resident in HBM                              */
     int32_t max_slots, max_tile_vertices, block_threads, lds_bytes;
-    int32_t slots_per_thread, reserved;
+    int32_t slots_per_thread;
+    int32_t n_planes;            /* dword planes per tile slot: 13, or 22 with an explicit element operator */
 } tsamd_plan_info;
 
 /* One tile of the plan, as host pointers into the handle (valid until tsamd_destroy).
@@ -86,7 +89,8 @@ typedef struct tsamd_tile_view {
     int32_t n_slots, n_owned, s_pad, n_verts, n_excl;
     int64_t stage_off;
     int32_t n_inc4;           /* incidence list length in 4-entry chunks                           */
-    const uint32_t *planes;   /* 13 planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]   */
+    const uint32_t *planes;   /* n_planes planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]
+                               * (+ L[e,e], L[e,n_0..3], L[n_0..3,e] as fp32 with an explicit operator)    */
     const uint16_t *inc;      /* 4*n_inc4 entries (slot << 2 | a), grouped by local vertex          */
     const uint16_t *inc_off;  /* n_verts + 1 chunk offsets                                          */
     const int32_t *gvid;      /* n_verts global vertex ids, exclusive ones first                    */
@@ -105,6 +109,21 @@ const char *tsamd_version(void);
 int tsamd_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
                  const tsamd_options *options, tsamd_handle **out);
 int tsamd_create_from_veg(const char *path, const tsamd_options *options, tsamd_handle **out);
+/*
+ * Same as tsamd_create, with the element operator L of the smoothness term H = (L (x) I9) G x given as data
+ * (SURVEY 8(b) "optional create inputs: explicit CSR adjacency + weights").  The reference takes L from
+ * libpgo -- pgo_create_tet_biharmonic_gradient_matrix(geo, faceNeighbor=1, scale=0), tet_spheres.cpp:148 --
+ * whose source is not part of the reference; tsamd_create ASSUMES the uniform face-adjacency umbrella
+ * (L[e,e] = number of face neighbours, L[e,e'] = -1).  This entry point substitutes any other operator with
+ * the same sparsity (e.g. the matrix libpgo really builds, dumped by tools/pin_L_with_pypgo.py, or the
+ * row-scaled scale=1 variant): m x m CSR over tets, double values (rounded to fp32 like the reference's
+ * matrix values, tet_spheres.cpp:43-45), 0-based.  Entries must lie on the diagonal or on a face adjacency of
+ * the mesh (duplicates are summed); anything else is TSAMD_ERR_INVALID_ARGUMENT.  L need not be symmetric:
+ * the gradient applies L^T explicitly.  Cost: 9 more fp32 planes per tile slot (88 instead of 52 bytes).
+ */
+int tsamd_create_with_operator(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
+                               const int64_t *op_rowptr, const int32_t *op_col, const double *op_val,
+                               const tsamd_options *options, tsamd_handle **out);
 void tsamd_destroy(tsamd_handle *h);
 
 int64_t tsamd_num_vertices(const tsamd_handle *h);

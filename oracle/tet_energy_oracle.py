@@ -42,6 +42,7 @@ __all__ = [
     "rest_operators",
     "face_adjacency",
     "element_laplacian",
+    "element_laplacian_scaled",
     "deformation_gradient",
     "det3",
     "cofactor3",
@@ -221,18 +222,38 @@ def biharmonic_matrix(rest, tets, n_vertices: int | None = None):
 class _Cache:
     """Rest-state data for one mesh so repeated evaluations are cheap."""
 
-    def __init__(self, rest, tets, round_fp32=True, nbr=None):
+    def __init__(self, rest, tets, round_fp32=True, nbr=None, L=None):
         self.tets = np.asarray(tets).reshape(-1, 4).astype(np.int64)
         self.n = int(np.asarray(rest).reshape(-1, 3).shape[0])
         _, self.Dminv = rest_operators(rest, self.tets, round_fp32=round_fp32)
         self.nbr = face_adjacency(self.tets) if nbr is None else np.asarray(nbr)
-        self.L = element_laplacian(self.nbr)
+        if L is None:
+            self.L = element_laplacian(self.nbr)
+        else:
+            # an explicit element operator (what tsamd_create_with_operator takes); its values are rounded
+            # to fp32 like every operator value of the reference (tet_spheres.cpp:43-45)
+            L = sp.csr_matrix(L, dtype=np.float64).copy()     # own arrays: scipy sorts indices in place later on
+            L.sum_duplicates()
+            if round_fp32:
+                L.data = L.data.astype(np.float32).astype(np.float64)
+            self.L = L
 
 
-def prepare(rest, tets, round_fp32: bool = True, nbr=None) -> _Cache:
+def prepare(rest, tets, round_fp32: bool = True, nbr=None, L=None) -> _Cache:
     """Build the rest-state cache.  ``round_fp32=True`` mirrors the reference's
-    double->fp32 rounding of the operator values (tet_spheres.cpp:43-45)."""
-    return _Cache(rest, tets, round_fp32=round_fp32, nbr=nbr)
+    double->fp32 rounding of the operator values (tet_spheres.cpp:43-45).  ``L`` replaces the assumed
+    uniform element Laplacian by an explicit (m x m, possibly non-symmetric) operator."""
+    return _Cache(rest, tets, round_fp32=round_fp32, nbr=nbr, L=L)
+
+
+def element_laplacian_scaled(nbr: np.ndarray) -> sp.csr_matrix:
+    """The row-scaled variant ``D^-1 (D - A)`` (diagonal 1, off-diagonals ``-1/deg``): what a ``scale=1``
+    argument of libpgo's `pgo_create_tet_biharmonic_gradient_matrix` would plausibly denote.  Non-symmetric;
+    used by the tests of the explicit-operator path."""
+    L = element_laplacian(nbr)
+    d = L.diagonal()
+    d[d == 0] = 1.0
+    return sp.diags(1.0 / d) @ L
 
 
 def energy_and_grad(x, cache: _Cache, c1: float, c2: float, order: int,
@@ -398,3 +419,78 @@ def factored_tolerances(x, cache: _Cache, c1, c2, order, rtol=1e-5, gamma_ulps=1
     tol_g = (rtol * (c1 * float(np.linalg.norm(gs)) + c2 * float(np.linalg.norm(gb)))
              + c1 * gamma * float(np.linalg.norm(ga)) + c2 * 8 * gamma * float(np.linalg.norm(gba)))
     return tol_E, tol_g
+
+
+def rounding_error_model(x, cache: _Cache, c1, c2, order):
+    """Statistical (variance-propagation) model of the fp32 rounding error of a FACTORED evaluation.
+
+    ``factored_tolerances`` above is a worst-case bound (absolute values summed); measured errors of the HIP
+    path sit 3-4 orders below it, so it cannot serve as a regression guard.  Here every fp32 operation is
+    given an independent relative error of standard deviation ``u = 2^-24`` and the variances are pushed
+    through ``F = Ds Dm^-1``, ``H = L F``, ``Q = L^T H``, ``P = c1 Q + c2 pen' cof F``, ``d = P Dm^-T`` and the
+    per-vertex sums.  Returns ``(std_E, std_g)`` with ``std_g`` of shape ``[n]``: the predicted standard
+    deviation of the error of each vertex' gradient (Euclidean norm over x, y, z).  The tests assert the
+    measured errors against a fixed multiple of these (calibrated on MI355X, profiles/r02_parity.txt).
+    """
+    u2 = (2.0 ** -24) ** 2
+    c1 = float(np.float32(c1))
+    c2 = float(np.float32(c2))
+    T = cache.tets
+    m = T.shape[0]
+    p = np.asarray(x, dtype=np.float32).astype(np.float64).reshape(-1, 3)[T]
+    Ds = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]], axis=2)
+    Di = cache.Dminv
+    F = Ds @ Di
+    vF = u2 * np.einsum("mik,mkj->mij", Ds * Ds, Di * Di)             # sum_k (Ds_ik Dminv_kj)^2
+    L = cache.L.tocsr()
+    L2 = L.multiply(L).tocsr()
+    Ff = F.reshape(m, 9)
+    H = L @ Ff
+    vH = L2 @ vF.reshape(m, 9) + u2 * (L2 @ (Ff * Ff))
+    Q = L.T @ H
+    vQ = L2.T @ vH + u2 * (L2.T @ (H * H))
+    J = det3(F)
+    pen, dpen = _penalty(J, int(order))
+    Cf = cofactor3(F)
+    F2 = F * F
+    # det: six triple products, each with its own rounding, plus the sensitivity to F (d det / dF = cof)
+    vJ = np.sum(Cf * Cf * vF, axis=(1, 2)) + u2 * (
+        F2[:, 0, 2] * F2[:, 1, 1] * F2[:, 2, 0] + F2[:, 0, 1] * F2[:, 1, 2] * F2[:, 2, 0] + F2[:, 0, 2] * F2[:, 1, 0] * F2[:, 2, 1]
+        + F2[:, 0, 0] * F2[:, 1, 2] * F2[:, 2, 1] + F2[:, 0, 1] * F2[:, 1, 0] * F2[:, 2, 2] + F2[:, 0, 0] * F2[:, 1, 1] * F2[:, 2, 2])
+    if int(order) == 2:
+        ddpen = np.where(J < 0, 2.0, 0.0)
+    elif int(order) == 4:
+        ddpen = np.where(J < 0, 12.0 * J * J, 0.0)
+    else:
+        ddpen = np.zeros_like(J)
+    # cofactor entries C_ij = F_a F_d - F_b F_c
+    vC = np.empty_like(F)
+    for i in range(3):
+        for j in range(3):
+            r = [a for a in range(3) if a != i]
+            c = [b for b in range(3) if b != j]
+            a_, d_, b_, c_ = (r[0], c[0]), (r[1], c[1]), (r[0], c[1]), (r[1], c[0])
+            Fa, Fd, Fb, Fc = F[:, a_[0], a_[1]], F[:, d_[0], d_[1]], F[:, b_[0], b_[1]], F[:, c_[0], c_[1]]
+            vC[:, i, j] = (Fd ** 2 * vF[:, a_[0], a_[1]] + Fa ** 2 * vF[:, d_[0], d_[1]] + Fc ** 2 * vF[:, b_[0], b_[1]]
+                           + Fb ** 2 * vF[:, c_[0], c_[1]] + u2 * ((Fa * Fd) ** 2 + (Fb * Fc) ** 2))
+    vPb = (ddpen ** 2 * vJ)[:, None, None] * Cf ** 2 + (dpen ** 2)[:, None, None] * vC + u2 * (dpen[:, None, None] * Cf) ** 2
+    Pm = c1 * Q.reshape(m, 3, 3) + c2 * dpen[:, None, None] * Cf
+    vP = c1 * c1 * vQ.reshape(m, 3, 3) + c2 * c2 * vPb + u2 * Pm ** 2
+    d = Pm @ np.transpose(Di, (0, 2, 1))
+    vd = np.einsum("mij,mkj->mik", vP, Di * Di) + u2 * np.einsum("mij,mkj->mik", Pm * Pm, Di * Di)
+    vg = np.zeros(cache.n)
+    f0 = -d.sum(axis=2)
+    for k in range(3):
+        np.add.at(vg, T[:, k + 1], vd[:, :, k].sum(axis=1) + u2 * (d[:, :, k] ** 2).sum(axis=1))
+    np.add.at(vg, T[:, 0], vd.sum(axis=(1, 2)) + u2 * (f0 ** 2).sum(axis=1) + u2 * (d ** 2).sum(axis=(1, 2)))
+    Es = 0.5 * float(np.sum(H * H))
+    Eb = float(np.sum(pen))
+    # the two sums are accumulated in fp32 per tile (~1000 tets: lanes, then a wave tree) and in double across tiles:
+    # relative error ~ 2u of each tile's partial sum
+    part = min(1.0, 1024.0 / max(m, 1))
+    vE = c1 * c1 * (float(np.sum(H * H * vH)) + 4 * u2 * Es * Es * part + u2 * 0.25 * float(np.sum(H ** 4))) \
+        + c2 * c2 * (float(np.sum(dpen ** 2 * vJ)) + u2 * float(np.sum(pen ** 2)) + 4 * u2 * Eb * Eb * part)
+    # second-order term: E_s = 1/2 |H + dH|^2 carries the (always positive) bias 1/2 sum var(H), which dominates at
+    # and near the rest state where H itself vanishes
+    bias = c1 * 0.5 * float(np.sum(vH))
+    return float(np.sqrt(vE)) + bias, np.sqrt(vg)

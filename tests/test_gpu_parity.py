@@ -6,7 +6,15 @@ float64 oracle on identical fp32 inputs.  Two tolerances are asserted everywhere
 * ``factored_tolerances`` (oracle/tet_energy_oracle.py): rtol 1e-5 plus the propagated
   16-ulp error model of a factored fp32 evaluation -- the bar for OUR kernels;
 * SURVEY.md 8(c)'s band for the reference formulation, ``1e-5*|E| + 8*eps*c1*A`` and the gradient
-  analogue, which the fp32 ``M = G^T L^T L G`` path itself needs.
+  analogue, which the fp32 ``M = G^T L^T L G`` path itself needs;
+* a REGRESSION GUARD: both of the above are worst-case bounds that sit 3-4 orders above the measured
+  errors (profiles/r01_parity.txt), so a kernel that lost 1000x accuracy, or corrupted one tile, would still
+  pass them.  ``oracle.rounding_error_model`` predicts the standard deviation of the fp32 rounding error of
+  the energy and of EVERY vertex' gradient by variance propagation; the guard asserts
+  ``|dE| <= GUARD_E * std_E``, ``|dg|_2 <= GUARD_G * |std_g|_2`` and, per vertex,
+  ``|dg_v| <= GUARD_V * (std_g_v + 1e-3 * rms(std_g))``.  Largest ratios measured on MI355X over this whole suite
+  (68 cases, profiles/r02_parity.txt lists every one): energy 6.1, gradient 0.66, worst vertex 3.9 -- the guard
+  factors leave 7-12x of head-room, the old tolerances left 1 000-10 000x.
 """
 import os
 
@@ -18,6 +26,8 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 EPS = 2.0 ** -23
+# regression guard factors: 7-12x the largest measured ratio err / predicted std (see profiles/r02_parity.txt)
+GUARD_E, GUARD_G, GUARD_V = 40.0, 8.0, 30.0
 
 
 @pytest.fixture(scope="module")
@@ -39,9 +49,9 @@ def _eval_gpu(ext, ts, x_np, c1, c2, order, go=1.0):
     return float(e), g.cpu().numpy().astype(np.float64)
 
 
-def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0, label=""):
+def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0, label="", L=None):
     O = _oracle()
-    cache = O.prepare(scene_rest, scene_tets)
+    cache = O.prepare(scene_rest, scene_tets, L=L)
     E, Es, Eb, g = O.energy_and_grad(x_np, cache, c1, c2, order, grad_output=go)
     tol_e, tol_g = O.factored_tolerances(x_np, cache, c1, c2, order)
     A, nMx = O.tolerance_scales(x_np, cache)
@@ -50,8 +60,19 @@ def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0,
     e_gpu, g_gpu = _eval_gpu(ext, ts, x_np, c1, c2, order, go)
     err_e = abs(e_gpu - E)
     err_g = float(np.linalg.norm(g_gpu - g))
+    std_e, std_gv = O.rounding_error_model(x_np, cache, c1, c2, order)
+    std_g = abs(go) * float(np.sqrt(np.sum(std_gv ** 2)))
+    err_v = np.linalg.norm(g_gpu - g, axis=1)
+    floor_v = abs(go) * (std_gv + 1e-3 * float(np.sqrt(np.mean(std_gv ** 2))))
+    ratio_v = float(np.max(err_v / np.maximum(floor_v, 1e-300))) if err_v.size else 0.0
+    if ratio_v > 20 and os.environ.get("TSSPLAT_AMD_PARITY_REPORT"):
+        k = int(np.argmax(err_v / np.maximum(floor_v, 1e-300)))
+        with open(os.environ["TSSPLAT_AMD_PARITY_REPORT"], "a") as fh:
+            fh.write(f"#   outlier vertex {k}: err {err_v[k]:.3e} std {abs(go) * std_gv[k]:.3e} |g_v| {np.linalg.norm(g[k]):.3e} gpu {g_gpu[k]} oracle {g[k]} "
+                     f"rms std {abs(go) * float(np.sqrt(np.mean(std_gv ** 2))):.3e} max std {abs(go) * float(std_gv.max()):.3e}\n")
     line = (f"[{label}] E={E:.6e} gpu={e_gpu:.6e} err={err_e:.2e} tol={tol_e:.2e} band={band_e:.2e} | "
-            f"|g|={np.linalg.norm(g):.4e} err={err_g:.2e} tol={abs(go) * tol_g:.2e} band={band_g:.2e}")
+            f"|g|={np.linalg.norm(g):.4e} err={err_g:.2e} tol={abs(go) * tol_g:.2e} band={band_g:.2e} | "
+            f"guard ratios err/std: E {err_e / max(std_e, 1e-300):.2f} g {err_g / max(std_g, 1e-300):.2f} vertex-max {ratio_v:.2f}")
     print(line)
     if os.environ.get("TSSPLAT_AMD_PARITY_REPORT"):      # profiles/r01_parity.txt is made this way
         with open(os.environ["TSSPLAT_AMD_PARITY_REPORT"], "a") as fh:
@@ -61,6 +82,10 @@ def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0,
     assert err_g <= abs(go) * tol_g, f"{label}: gradient error {err_g:.3e} > factored tolerance {abs(go) * tol_g:.3e}"
     assert err_e <= band_e + tol_e
     assert err_g <= band_g + abs(go) * tol_g
+    # regression guard (module docstring): a few standard deviations of the predicted fp32 rounding error
+    assert err_e <= GUARD_E * std_e, f"{label}: energy error {err_e:.3e} > {GUARD_E} x predicted std {std_e:.3e}"
+    assert err_g <= GUARD_G * std_g, f"{label}: gradient error {err_g:.3e} > {GUARD_G} x predicted std {std_g:.3e}"
+    assert ratio_v <= GUARD_V, f"{label}: a vertex is off by {ratio_v:.1f} predicted standard deviations"
     # energy terms individually
     es_gpu, eb_gpu = ts.energy_terms()
     assert abs(es_gpu - Es) <= tol_e / max(float(np.float32(c1)), 1e-30) + 1e-12
@@ -120,7 +145,7 @@ def test_unstructured_delaunay(ext, seed):
 
 
 def test_cone_hub_vertex(ext):
-    """One vertex of valence 1280: LDS-atomic contention must not change the result."""
+    """One vertex of valence 1280 (hub of a cone of triangles): its incidence list spans many chunks."""
     from tssplat_amd import scenes
     sc = scenes.make_scene("cone", 5)
     ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
@@ -353,3 +378,90 @@ def test_random_tiling_options_on_gpu(ext):
                        go=float(rng.choice([1.0, 0.25])), label=f"random#{trial} {kind} {kw}")
         ran += 1
     assert ran >= 10
+
+
+@pytest.mark.parametrize("kind,S,kw", [("kuhn8", 8, {}), ("kuhn19", 2, {}), ("kuhn19", 2, dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840)),
+                                       ("delaunay3000", 3, {})])
+def test_explicit_operator_parity(ext, kind, S, kw):
+    """tsamd_create_with_operator: the element operator L as data.  The row-scaled umbrella
+    (non-symmetric: the gradient needs L^T), random weights, and the assumed uniform operator passed explicitly
+    (must agree with the built-in path to rounding)."""
+    from tssplat_amd import scenes
+    O = _oracle()
+    sc = scenes.make_scene(kind, S)
+    nbr = O.face_adjacency(sc.tets)
+    rng = np.random.default_rng(11)
+    import scipy.sparse as sp
+    m = sc.n_tets
+    rows = np.repeat(np.arange(m), 4)
+    cols = nbr.ravel()
+    ok = cols >= 0
+    Lr = (sp.diags(rng.uniform(1.0, 5.0, m)) + sp.csr_matrix((rng.uniform(-2.0, -0.2, ok.sum()), (rows[ok], cols[ok])), shape=(m, m))).tocsr()
+    for name, L in (("scaled", O.element_laplacian_scaled(nbr)), ("random", Lr), ("uniform", O.element_laplacian(nbr))):
+        ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), operator=L, **kw)
+        assert ts.plan_info()["n_planes"] == 22
+        for sigma, order in ((0.02, 2), (0.3, 4)):
+            x = scenes.deform(sc, sigma)
+            _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / S, 2e-4, order, go=0.5, L=L,
+                           label=f"operator={name} {kind}x{S} {kw} s={sigma} p={order}")
+    # explicit uniform == built-in
+    ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), **kw)
+    x = scenes.deform(sc, 0.1)
+    e_d, g_d = _eval_gpu(ext, ts_d, x, 2e-4 / S, 2e-4, 2)
+    e_x, g_x = _eval_gpu(ext, ts, x, 2e-4 / S, 2e-4, 2)
+    assert abs(e_d - e_x) <= 2e-6 * abs(e_d) and np.linalg.norm(g_d - g_x) <= 2e-6 * np.linalg.norm(g_d)
+
+
+def test_reference_spelling_of_the_autograd_function(ext):
+    """The Function exactly as /root/reference/energies/smooth_barrier.py:9-31 spells it -- `forward` WITHOUT ctx +
+    `setup_context`, saved tensor `x_cur`, constants on ctx, `int(order)` on the way back -- executed on the GPU
+    over this repo's `tet_spheres_ext`, in the reference's return convention (CPU 0-dim energy, so the
+    grad_output that comes back is a CPU 0-dim tensor as well, tet_spheres_cuda.cu:194,257)."""
+    from tssplat_amd import scenes
+    from tet_spheres import tet_spheres_ext                     # the reference's import path (smooth_barrier.py:6)
+
+    class SmoothnessBarrierFunc(torch.autograd.Function):
+        @staticmethod
+        def forward(x_cur, tet_sp, c1, c2, order):
+            return tet_spheres_ext.forward(x_cur, tet_sp, c1, c2, order)
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            x_cur, tet_sp, c1, c2, order = inputs
+            ctx.save_for_backward(x_cur)
+            ctx.constants = (tet_sp, c1, c2, order)
+
+        @staticmethod
+        def backward(ctx, grad_output):
+            if grad_output is None:
+                return None, None, None, None, None
+            x_cur, = ctx.saved_tensors
+            tet_sp, c1, c2, order = ctx.constants
+            grad_final = tet_spheres_ext.backward(grad_output, x_cur, tet_sp, c1, c2, int(order))
+            return grad_final, None, None, None, None
+
+    sc = scenes.make_scene("kuhn8", 5)
+    v_flat = sc.rest.flatten().astype(np.float32)                # smooth_barrier.py:38-40
+    f_flat = sc.tets.flatten().astype(np.int32)
+    tet_sp = tet_spheres_ext.TetSpheres(v_flat, f_flat)
+    x_np = scenes.deform(sc, 0.3)
+    O = _oracle()
+    cache = O.prepare(sc.rest, sc.tets)
+    c1, c2 = 2e-4 / 5, 2e-4
+    prev = tet_spheres_ext.CPU_ENERGY
+    tet_spheres_ext.CPU_ENERGY = True
+    try:
+        for order in (2, 4):
+            x = torch.nn.Parameter(torch.from_numpy(x_np).cuda())
+            e = SmoothnessBarrierFunc.apply(x, tet_sp, c1, c2, order)
+            assert e.dim() == 0 and e.dtype == torch.float32 and not e.is_cuda          # .cu:194
+            img_loss = (x * x).sum() * 0.0 + 1.0                                        # a CUDA scalar, as trainer.py:115 adds
+            loss = img_loss * 100 + 1.7 * e
+            loss.backward()
+            E, _, _, g = O.energy_and_grad(x_np, cache, c1, c2, order, grad_output=1.7)
+            std_e, std_gv = O.rounding_error_model(x_np, cache, c1, c2, order)
+            assert abs(float(e) - E) <= GUARD_E * std_e
+            assert np.linalg.norm(x.grad.cpu().numpy() - g) <= GUARD_G * 1.7 * float(np.sqrt(np.sum(std_gv ** 2)))
+            assert x.grad.shape == x.shape and x.grad.device == x.device
+    finally:
+        tet_spheres_ext.CPU_ENERGY = prev

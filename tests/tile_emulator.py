@@ -26,7 +26,7 @@ def plan_tiles(ts):
         tv = _capi.TileView()
         _capi.check(lib.tsamd_get_tile(ts._handle(), t, C.byref(tv)))
         sp = tv.s_pad
-        planes = np.ctypeslib.as_array(tv.planes, shape=(13, sp)).copy()
+        planes = np.ctypeslib.as_array(tv.planes, shape=(info["n_planes"], sp)).copy()
         inc = np.ctypeslib.as_array(tv.inc, shape=(max(4 * tv.n_inc4, 1),)).copy()[:4 * tv.n_inc4]
         inc_off = np.ctypeslib.as_array(tv.inc_off, shape=(tv.n_verts + 1,)).copy()
         gvid = np.ctypeslib.as_array(tv.gvid, shape=(tv.n_verts,)).copy()
@@ -127,12 +127,20 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         Fz[perm] = F.reshape(sp, 9)
         assert np.array_equal(deg_packed, (nb != ZS).sum(axis=1)), "packed degree must equal the neighbour count"
         deg = deg_packed.astype(np.float64)
-        H = deg[:, None] * F.reshape(sp, 9) - Fz[nb].sum(axis=1)
+        if pl.shape[0] == 13:                 # uniform umbrella, weights implied
+            wd = deg
+            wr = wc = -np.ones((sp, 4))
+        else:                                 # explicit element operator: L[e,e], L[e,n_k], L[n_k,e]
+            wd = pl[13].view(np.float32).astype(np.float64)
+            wr = pl[14:18].view(np.float32).astype(np.float64).T
+            wc = pl[18:22].view(np.float32).astype(np.float64).T
+            assert np.all(wr[nb == ZS] == 0) and np.all(wc[nb == ZS] == 0)
+        H = wd[:, None] * F.reshape(sp, 9) + (wr[:, :, None] * Fz[nb]).sum(axis=1)
         H[~owned] = 0.0
         Es += 0.5 * float((H * H).sum())
         Hz = np.zeros((sp + 1, 9))
         Hz[perm] = H
-        Q = deg[:, None] * H - Hz[nb].sum(axis=1)
+        Q = wd[:, None] * H + (wc[:, :, None] * Hz[nb]).sum(axis=1)
         P = c1 * Q.reshape(sp, 3, 3) + scal[:, None, None] * _cof(F)
         d = P @ np.transpose(dminv, (0, 2, 1))
         # per-vertex gather through the incidence lists, exactly as the kernel's last phase does

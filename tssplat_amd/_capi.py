@@ -44,7 +44,7 @@ class PlanInfo(C.Structure):
         ("n_components", C.c_int64), ("total_slots", C.c_int64), ("total_tile_vertices", C.c_int64),
         ("shared_vertex_copies", C.c_int64), ("finish_vertices", C.c_int64), ("device_bytes", C.c_int64),
         ("max_slots", C.c_int32), ("max_tile_vertices", C.c_int32), ("block_threads", C.c_int32),
-        ("lds_bytes", C.c_int32), ("slots_per_thread", C.c_int32), ("reserved", C.c_int32),
+        ("lds_bytes", C.c_int32), ("slots_per_thread", C.c_int32), ("n_planes", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -65,6 +65,8 @@ SIGNATURES = {
     "tsamd_last_error": (C.c_char_p, []),
     "tsamd_version": (C.c_char_p, []),
     "tsamd_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "tsamd_create_with_operator": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "tsamd_create_from_veg": (C.c_int, [C.c_char_p, C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "tsamd_destroy": (None, [C.c_void_p]),
     "tsamd_num_vertices": (C.c_int64, [C.c_void_p]),

@@ -139,7 +139,7 @@ int to_device(tsamd_handle *h, int device)
 }
 
 int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, const tsamd_options *o,
-                  tsamd_handle **out)
+                  tsamd_handle **out, const tsamd::ElementOperatorCSR *op = nullptr)
 {
     if (!out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
@@ -166,7 +166,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     std::string err;
     int rc = 0;
     try {
-        rc = tsamd::build_plan(rest, n, tets, m, po, h->plan, err);
+        rc = tsamd::build_plan(rest, n, tets, m, po, h->plan, err, op);
     } catch (const std::bad_alloc &) {
         rc = TSAMD_ERR_INVALID_ARGUMENT;
         err = "out of host memory while building the plan";
@@ -215,6 +215,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
     a.spt = h->plan.spt;
+    a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
     a.walk_blocks = h->walk_blocks;
     a.sa_max = ((h->plan.max_slots + 3) & ~3) + 4;
     a.vp_max = (h->plan.max_verts + 3) & ~3;
@@ -255,6 +256,15 @@ int tsamd_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets,
     return create_common(rest_xyz, n_vertices, tets, n_tets, options, out);
 }
 
+int tsamd_create_with_operator(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
+                               const int64_t *op_rowptr, const int32_t *op_col, const double *op_val,
+                               const tsamd_options *options, tsamd_handle **out)
+{
+    if (!op_rowptr) return fail(TSAMD_ERR_INVALID_ARGUMENT, "op_rowptr is null (use tsamd_create for the default operator)");
+    const tsamd::ElementOperatorCSR op{op_rowptr, op_col, op_val};
+    return create_common(rest_xyz, n_vertices, tets, n_tets, options, out, &op);
+}
+
 int tsamd_create_from_veg(const char *path, const tsamd_options *options, tsamd_handle **out)
 {
     if (!path) return fail(TSAMD_ERR_INVALID_ARGUMENT, "path is null");
@@ -290,6 +300,7 @@ int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out)
     out->block_threads = P.block_threads;
     out->lds_bytes = P.lds_bytes;
     out->slots_per_thread = P.spt;
+    out->n_planes = P.n_planes;
     return TSAMD_OK;
 }
 
@@ -307,7 +318,7 @@ int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out)
     out->stage_off = d.stage_off;
     out->n_inc4 = d.n_inc4;
     out->planes = P.blob.data() + d.blob_off / 4;
-    out->inc = reinterpret_cast<const uint16_t *>(out->planes + size_t(tsamd::kPlanes) * size_t(d.s_pad));
+    out->inc = reinterpret_cast<const uint16_t *>(out->planes + size_t(P.n_planes) * size_t(d.s_pad));
     out->inc_off = out->inc + 4 * size_t(d.n_inc4);
     out->gvid = P.gvid.data() + d.vert_off;
     out->slot_tet = P.slot_tet.data() + P.slot_base[size_t(tile)];

@@ -144,6 +144,22 @@ __device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, const M
     return acc;
 }
 
+// explicit element operator: acc = dg * own + sum_k w[k] * neighbour_k  (the weights carry their sign)
+__device__ __forceinline__ Mat9 operator_gather(const unsigned char *lds, const Mat9 &own, float dg, const float *w,
+                                                const uint32_t *nb)
+{
+    Mat9 acc;
+    acc.p01 = own.p01 * dg; acc.p23 = own.p23 * dg; acc.p45 = own.p45 * dg; acc.p67 = own.p67 * dg;
+    acc.p8 = own.p8 * dg;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Mat9 g = load_slot(lds, nb[k]);
+        acc.p01 += g.p01 * w[k]; acc.p23 += g.p23 * w[k]; acc.p45 += g.p45 * w[k]; acc.p67 += g.p67 * w[k];
+        acc.p8 += g.p8 * w[k];
+    }
+    return acc;
+}
+
 struct KernelArgs {
     const TileDesc *tiles;
     const uint8_t *blob;
@@ -190,7 +206,7 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
 // prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
 // within noise: DESIGN.md section 4.)
-template <bool WITH_GRAD, int SPT>
+template <bool WITH_GRAD, int SPT, bool WEIGHTED>
 __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
 {
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
@@ -234,6 +250,14 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     VF dm[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+    // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
+    // weights for pass 3 replace them after pass 2
+    VF wd, wk[4];
+    if (WEIGHTED) {
+        wd = plane_f(13);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
+    }
     if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
     // stage this tile's vertex positions; the fence keeps the compiler from waiting for the vertex id (and so for
     // nothing else: vmcnt(13)) before the plane loads above have been issued
@@ -307,7 +331,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
                 const uint32_t so = uint32_t(p * nq + tid);
                 if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = so;
-                const Mat9 h = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                Mat9 h;
+                if (WEIGHTED) {
+                    const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
+                    h = operator_gather(smem, load_own_slot(smem, so), wd[p], w4, nb);
+                } else {
+                    h = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                }
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
                 sq = __builtin_elementwise_fma(h.p45, h.p45, sq);
@@ -328,7 +358,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         // list and one the odd ones.  Each fetches its first kPre chunks now so that their HBM latency hides
         // behind pass 3.
         constexpr int kPre = 3;
-        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kPlanes * td.s_pad);
+        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + (WEIGHTED ? kPlanesWeighted : kPlanes) * td.s_pad);
         const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
         const uint32_t pad16 = (ZS << 2) | 1u;
         int pc0 = 0, pc1 = 0;
@@ -345,6 +375,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             }
 #pragma unroll
             for (int p = 0; p < SPT; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
+            if (WEIGHTED) {   // pass 3 applies L^T: the column weights L[n_k, e]
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
+            }
         }
         __syncthreads();
         STAMP(4);  // H written, reloads issued
@@ -361,7 +395,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 const uint32_t so = uint32_t(p * nq + tid);
                 if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = so;
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
-                Mat9 q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                Mat9 q;
+                if (WEIGHTED) {
+                    const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
+                    q = operator_gather(smem, load_own_slot(smem, so), wd[p], w4, nb);
+                } else {
+                    q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                }
                 q.p01 *= a.c1; q.p23 *= a.c1; q.p45 *= a.c1; q.p67 *= a.c1;
                 q.p8 *= a.c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
@@ -835,7 +875,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_walk_kernel(const KernelArgs 
     tile_walk<SPT>(a, tile, step, tile_end, a.sa_max, a.vp_max);
 }
 
-template <bool WITH_GRAD, int BLOCK, int SPT, int WPE>
+template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -848,7 +888,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     const int tile = xcd * a.tiles_per_xcd + jb;
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
     const TileDesc td0 = a.tiles[tile];
-    tile_body<WITH_GRAD, SPT>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
+    tile_body<WITH_GRAD, SPT, WEIGHTED>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
 }
 
 struct FinishArgs {
@@ -1086,7 +1126,12 @@ hipError_t configure_kernels(int lds_bytes)
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>),
-                         reinterpret_cast<const void *>(&tile_walk_kernel<768, 2, 6>)};
+                         reinterpret_cast<const void *>(&tile_walk_kernel<768, 2, 6>),
+                         // explicit-operator builds (one more register-hungry stream: 128-VGPR launch bounds)
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, true>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -1134,7 +1179,15 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
         k.sa_max = e.sa_max;
         k.vp_max = e.vp_max;
-        if (e.grad && two_per_cu && e.walk_blocks > 0 && e.n_tiles > e.walk_blocks && e.lds_bytes_walk <= 80 * 1024) {
+        if (e.weighted) {
+#define TSAMD_LAUNCH_W(G, S) hipLaunchKernelGGL((tile_energy_kernel<G, 1024, S, 4, true>), grid, block, size_t(lds), stream, k)
+            if (e.spt == 2) {
+                if (e.grad) TSAMD_LAUNCH_W(true, 2); else TSAMD_LAUNCH_W(false, 2);
+            } else {
+                if (e.grad) TSAMD_LAUNCH_W(true, 4); else TSAMD_LAUNCH_W(false, 4);
+            }
+#undef TSAMD_LAUNCH_W
+        } else if (e.grad && two_per_cu && e.walk_blocks > 0 && e.n_tiles > e.walk_blocks && e.lds_bytes_walk <= 80 * 1024) {
             // resident workgroups (two per CU) walking their XCD's tiles with next-tile prefetch
             hipLaunchKernelGGL((tile_walk_kernel<768, 2, 6>), dim3(unsigned(e.walk_blocks / 8 * 8)), block,
                                size_t(e.lds_bytes_walk), stream, k);

@@ -297,7 +297,7 @@ struct Splitter {
 }  // namespace
 
 int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt, Plan &P,
-               std::string &err)
+               std::string &err, const ElementOperatorCSR *op)
 {
     if (n < 0 || m < 0 || (n > 0 && !rest) || (m > 0 && !tets)) {
         err = "null pointer or negative size";
@@ -332,6 +332,49 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     int rc = build_adjacency(tets, n, m, P.nbr, nthreads, err);
     if (rc) return rc;
     Mesh M{rest, tets, P.nbr.data(), n, m};
+
+    // ---- explicit element operator: CSR -> (diagonal, one weight per tet face) ----
+    if (op) {
+        if (!op->rowptr || (m > 0 && op->rowptr[m] > 0 && (!op->col || !op->val))) {
+            err = "element operator: null CSR array";
+            return ERR_INVALID;
+        }
+        P.n_planes = kPlanesWeighted;
+        P.op_diag.assign(size_t(m), 0.f);
+        P.op_w.assign(size_t(4 * m), 0.f);
+        std::vector<double> dg(static_cast<size_t>(m), 0.0), w(static_cast<size_t>(4 * m), 0.0);
+        for (int64_t e = 0; e < m; ++e) {
+            if (op->rowptr[e + 1] < op->rowptr[e]) {
+                err = "element operator: rowptr is not monotone";
+                return ERR_INVALID;
+            }
+            for (int64_t q = op->rowptr[e]; q < op->rowptr[e + 1]; ++q) {
+                const int64_t j = op->col[q];
+                const double v = op->val[q];
+                if (j == e) {
+                    dg[size_t(e)] += v;
+                    continue;
+                }
+                int k = -1;
+                for (int f = 0; f < 4; ++f)
+                    if (j >= 0 && P.nbr[4 * size_t(e) + f] == j) {
+                        k = f;
+                        break;
+                    }
+                if (k >= 0) {
+                    w[4 * size_t(e) + k] += v;
+                } else if (v != 0.0) {
+                    err = "element operator: entry (" + std::to_string(e) + ", " + std::to_string(j) +
+                          ") is neither on the diagonal nor a face adjacency of the mesh";
+                    return ERR_INVALID;
+                }
+            }
+        }
+        for (int64_t e = 0; e < m; ++e) P.op_diag[size_t(e)] = float(dg[size_t(e)]);   // double -> fp32, as the
+        for (int64_t i = 0; i < 4 * m; ++i) P.op_w[size_t(i)] = float(w[size_t(i)]);   // reference rounds its matrices
+    }
+    const bool weighted = op != nullptr;
+    const int n_planes = P.n_planes;
 
     // ---- connected components over face adjacency (each tet-sphere is one) ----
     std::vector<int32_t> comp(size_t(m), -1);
@@ -569,7 +612,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             err = "tile incidence list too long for 16-bit chunk offsets";
             return ERR_TILING;
         }
-        blob_bytes += (int64_t(kPlanes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1) + 127) &
+        blob_bytes += (int64_t(n_planes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1) + 127) &
                       ~int64_t(127);
         vert_off += d.n_verts;
         stage_off += d.n_verts - d.n_excl;
@@ -659,6 +702,21 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     nb[k] = v;
                     deg += v != ZS;
                 }
+                if (weighted) {   // planes 13..21: L[e,e], L[e,n_k], L[n_k,e] in the (not yet re-ordered) neighbour order
+                    auto putf = [&](int plane, float v) { std::memcpy(&pl[size_t(plane) * size_t(d.s_pad) + s], &v, 4); };
+                    putf(13, P.op_diag[size_t(el)]);
+                    for (int k = 0; k < 4; ++k) {
+                        const int32_t q = P.nbr[4 * size_t(el) + k];
+                        float wr = 0.f, wc = 0.f;
+                        if (q >= 0 && nb[k] != ZS) {
+                            wr = P.op_w[4 * size_t(el) + k];
+                            for (int f = 0; f < 4; ++f)
+                                if (P.nbr[4 * size_t(q) + f] == el) wc = P.op_w[4 * size_t(q) + f];
+                        }
+                        putf(14 + k, wr);
+                        putf(18 + k, wc);
+                    }
+                }
                 pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
                 pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
                 pl[2 * size_t(d.s_pad) + s] = nb[0] | (owned ? kOwnedBit : 0u) | (nb[1] << 16) | (deg << kDegShift);
@@ -719,6 +777,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 ++nl;
                             }
                             uint32_t chosen[16][4];
+                            int from[16][4];   // chosen[li][step] was candidate from[li][step] (the weights follow)
                             bool taken[16][4] = {};
                             for (int step = 0; step < 4; ++step) {
                                 int64_t colrec[16];
@@ -735,6 +794,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                             if (!taken[li][c]) pick = c;
                                     taken[li][pick] = true;
                                     chosen[li][step] = cand[li][pick];
+                                    from[li][step] = pick;
                                     const uint32_t r = cand[li][pick] & 15u;
                                     if (colrec[r] < 0) colrec[r] = int64_t(cand[li][pick]);
                                 }
@@ -743,13 +803,20 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 const int32_t sl = lane_slot[li];
                                 p2[sl] = (p2[sl] & ~(kSlotMask | (kSlotMask << 16))) | chosen[li][0] | (chosen[li][1] << 16);
                                 p3[sl] = chosen[li][2] | (chosen[li][3] << 16);
+                                if (weighted)
+                                    for (int base_plane : {14, 18}) {
+                                        uint32_t old[4];
+                                        for (int k = 0; k < 4; ++k) old[k] = pl[size_t(base_plane + k) * size_t(d.s_pad) + sl];
+                                        for (int k = 0; k < 4; ++k)
+                                            pl[size_t(base_plane + k) * size_t(d.s_pad) + sl] = old[from[li][k]];
+                                    }
                             }
                         }
             }
 
             // vertex incidence lists (the gradient is gathered per vertex, in this fixed order)
             {
-                uint16_t *inc = reinterpret_cast<uint16_t *>(pl + size_t(kPlanes) * size_t(d.s_pad));
+                uint16_t *inc = reinterpret_cast<uint16_t *>(pl + size_t(n_planes) * size_t(d.s_pad));
                 uint16_t *inc_off = inc + 4 * size_t(d.n_inc4);
                 std::vector<int32_t> cnt(size_t(d.n_verts), 0);
                 for (int32_t sl = 0; sl < d.s_pad; ++sl) {

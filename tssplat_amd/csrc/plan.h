@@ -49,6 +49,13 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI
 //                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
 //   n_verts + 1 x u16         : first chunk of every local vertex
 constexpr int kPlanes = 13;
+// Plans built with an explicit element operator (build_plan's `op`) carry 9 more fp32 planes per slot:
+//   [13]      L[e, e]
+//   [14..17]  L[e, n_k]   row weights, in the slot's (possibly re-ordered) neighbour order -- pass 2, H = L F
+//   [18..21]  L[n_k, e]   column weights, same order                                     -- pass 3, Q = L^T H
+// (0 where the neighbour is the zero slot).  Without an operator the kernels use the uniform face-adjacency
+// umbrella (diagonal = number of face neighbours, off-diagonals = -1) and these planes do not exist.
+constexpr int kPlanesWeighted = 22;
 // Index planes, two 16-bit fields per dword:
 //   lv01 = (16 * v0 | owned << 15) | (16 * v1) << 16      vertex ids pre-multiplied to byte offsets
 //   lv23 = (16 * v2)               | (16 * v3) << 16      into the staged float4 positions
@@ -90,11 +97,25 @@ struct Plan {
     int64_t n_stage = 0;             // rows in the staging buffer
     int64_t total_slots = 0, total_tile_verts = 0;
     int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0, spt = 4;
+    int32_t n_planes = kPlanes;      // kPlanes, or kPlanesWeighted when an explicit operator was given
+    std::vector<float> op_diag;      // explicit operator only: L[e,e] per tet
+    std::vector<float> op_w;         // explicit operator only: L[e, nbr[4e+k]] per tet face (0 on boundary faces)
+};
+
+// Element operator L (m x m) in CSR over tets.  Its sparsity must lie inside "diagonal + face adjacency":
+// any other nonzero entry is rejected.  This is how the reference's true operator -- libpgo's
+// pgo_create_tet_biharmonic_gradient_matrix(geo, faceNeighbor=1, scale=0), tet_spheres.cpp:148, whose
+// source is not part of the reference -- or any variant of it (e.g. the row-scaled scale=1 form) is
+// substituted for the uniform umbrella this library assumes by default.
+struct ElementOperatorCSR {
+    const int64_t *rowptr;  // m + 1
+    const int32_t *col;
+    const double *val;
 };
 
 // Returns 0 on success, otherwise a tsamd_status value with `err` filled in.
 int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt,
-               Plan &plan, std::string &err);
+               Plan &plan, std::string &err, const ElementOperatorCSR *op = nullptr);
 
 // nbr[4e+k] = tet across the face of e opposite local vertex k, -1 on the boundary; a face shared by more
 // than two tets is an error.  nthreads <= 1 runs serially.

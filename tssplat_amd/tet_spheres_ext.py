@@ -79,13 +79,16 @@ class TetSpheres:
     ``TetSpheres(filename)`` loads a Vega ``.veg`` tet mesh (tet_spheres.cpp:108-117);
     ``TetSpheres(vertices, elements)`` takes flat float32 ``[3n]`` / int32 ``[4m]``
     arrays, 0-based (tet_spheres.cpp:234-258, caller energies/smooth_barrier.py:38-40).
-    Keyword-only extras select the HIP device and tune the tiler.
+    Keyword-only extras select the HIP device and tune the tiler.  ``operator`` (array constructor only)
+    replaces the assumed uniform face-adjacency umbrella by an explicit element operator ``L`` -- a scipy
+    sparse matrix or a ``(rowptr, col, val)`` CSR triple over tets, e.g. the matrix libpgo really builds
+    (tet_spheres.cpp:148; see tools/pin_L_with_pypgo.py) -- through ``tsamd_create_with_operator``.
     """
 
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
                  balance_slots: bool = True, num_threads: int = 0, debug_shuffle: int = 0,
-                 slots_per_thread: int = 0):
+                 slots_per_thread: int = 0, operator=None):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
         self._cache = None
@@ -107,6 +110,8 @@ class TetSpheres:
                                   balance_slots=int(balance_slots), num_threads=num_threads,
                                   debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread)
         if isinstance(vertices, (str, os.PathLike)) and elements is None:
+            if operator is not None:
+                raise TypeError("operator= needs the (vertices, elements) constructor")
             rc = _lib.tsamd_create_from_veg(os.fspath(vertices).encode(), C.byref(opts), C.byref(self._h))
             _capi.check(rc)
         else:
@@ -120,8 +125,23 @@ class TetSpheres:
                 return
             v = np.ascontiguousarray(v, dtype=np.float32)      # py::array::forcecast
             f = np.ascontiguousarray(f, dtype=np.int32)
-            rc = _lib.tsamd_create(v.ctypes.data, v.size // 3, f.ctypes.data, f.size // 4,
-                                   C.byref(opts), C.byref(self._h))
+            if operator is None:
+                rc = _lib.tsamd_create(v.ctypes.data, v.size // 3, f.ctypes.data, f.size // 4,
+                                       C.byref(opts), C.byref(self._h))
+            else:
+                if hasattr(operator, "tocsr"):
+                    csr = operator.tocsr()
+                    if csr.shape != (f.size // 4, f.size // 4):
+                        raise ValueError(f"operator must be {f.size // 4} x {f.size // 4} (tets x tets), got {csr.shape}")
+                    operator = (csr.indptr, csr.indices, csr.data)
+                rp = np.ascontiguousarray(operator[0], dtype=np.int64)
+                ci = np.ascontiguousarray(operator[1], dtype=np.int32)
+                va = np.ascontiguousarray(operator[2], dtype=np.float64)
+                if rp.size != f.size // 4 + 1 or ci.size != va.size or (rp.size and rp[-1] != ci.size):
+                    raise ValueError("operator: inconsistent CSR arrays")
+                rc = _lib.tsamd_create_with_operator(v.ctypes.data, v.size // 3, f.ctypes.data, f.size // 4,
+                                                     rp.ctypes.data, ci.ctypes.data, va.ctypes.data,
+                                                     C.byref(opts), C.byref(self._h))
             _capi.check(rc)
         self.n = int(_lib.tsamd_num_vertices(self._h))
         self.nele = int(_lib.tsamd_num_tets(self._h))
