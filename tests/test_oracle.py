@@ -180,3 +180,45 @@ def test_property_gradient_is_derivative(k, seed, sigma, order):
     dd = (E64(xp) - E64(xm)) / (2 * h)
     assert abs(dd - float(np.sum(g * dx))) <= 1e-5 * max(1.0, abs(dd), np.linalg.norm(g))
     assert idx.size == x.size
+
+
+def test_pin_tool_identifies_the_operator():
+    """tools/pin_L_with_pypgo.py is the one-command route from "L unpinned" to "pinned" on a machine with libpgo.
+    Its comparison logic is exercised here on stand-in "libpgo" matrices built by the oracle (transposed vec(F)
+    row order included): each candidate operator must be recognised as itself."""
+    import importlib.util
+    import scipy.sparse as sp
+    from tssplat_amd import scenes
+    spec = importlib.util.spec_from_file_location("pin_tool", os.path.join(os.path.dirname(__file__), "..", "tools", "pin_L_with_pypgo.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    v, t = scenes.kuhn_ball(3)
+    rest = v.astype(np.float32)
+    n, m = rest.shape[0], t.shape[0]
+    G = O.gradient_operator_sparse(rest, t, n)
+    perm = np.arange(9).reshape(3, 3).T.ravel()
+    Pm = sp.kron(sp.identity(m), sp.csr_matrix((np.ones(9), (np.arange(9), perm)), shape=(9, 9)), format="csr")
+    nbr = O.face_adjacency(t)
+    for name, L in (("uniform", O.element_laplacian(nbr)), ("scaled", O.element_laplacian_scaled(nbr)),
+                    ("vertex-neighbours", tool.vertex_neighbour_laplacian(t))):
+        LG = sp.kron(L, sp.identity(9), format="csr") @ G
+        winner, err, dG = tool.compare((LG.T @ LG).tocsr(), (Pm @ G).tocsr(), rest, t, verbose=False)
+        assert winner == name and err <= 1e-12 and dG <= 1e-12
+
+
+def test_libpgo_pin_if_present(golden_dir):
+    """Once tools/pin_L_with_pypgo.py has been run on a machine with libpgo, its output pins L: the oracle's
+    M = G^T L^T L G for the recorded operator must reproduce libpgo's GTLTLG on the reference's a.veg."""
+    import scipy.sparse as sp
+    path = os.path.join(golden_dir, "libpgo_operator_pin.npz")
+    if not os.path.exists(path):
+        pytest.skip("L is PARITY UNPINNED: libpgo has not been available to any builder yet (tools/pin_L_with_pypgo.py)")
+    z = np.load(path)
+    mesh = np.load(os.path.join(golden_dir, "aveg_mesh.npz"))
+    rest, tets = mesh["rest"], mesh["tets"]
+    n, m = int(z["n"]), int(z["m"])
+    assert (n, m) == (rest.shape[0], tets.shape[0])
+    M_pgo = sp.coo_matrix((z["M_val"], (z["M_row"], z["M_col"])), shape=(3 * n, 3 * n)).tocsr()
+    assert str(z["winner"]) == "uniform", "libpgo's operator is not the one this library assumes by default"
+    M, _ = O.biharmonic_matrix(rest, tets, n)
+    assert abs(M - M_pgo).max() <= 1e-9 * abs(M_pgo).max()

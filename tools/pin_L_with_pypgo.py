@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Turn "L is PARITY UNPINNED" into "pinned" on any machine that has libpgo.
+
+The one arithmetic piece of the hot path the reference does not contain is the element operator L:
+`pgo_create_tet_biharmonic_gradient_matrix(tetMeshGeo, 1, 0)` (/root/reference/tssplat_ext/tet_spheres/
+tet_spheres.cpp:148) comes from the un-vendored, un-versioned libpgo (github.com/bohanwang/libpgo).  This
+repo ASSUMES the uniform face-adjacency umbrella (diagonal = number of face neighbours, off-diagonal -1).
+This script asks libpgo itself, through exactly the C calls the reference makes (tet_spheres.cpp:21,112,
+148-149,34-41), for `GTLTLG` and `G` of a mesh (default: the reference's own tssplat_ext/a.veg), and diffs
+them against `oracle.biharmonic_matrix` for every candidate operator:
+
+    uniform            L = D - A over face neighbours                (the assumption)
+    scaled             L = D^-1 (D - A)                              (what scale=1 would plausibly mean)
+    vertex-neighbours  L = D - A over tets sharing a vertex          (what faceNeighbor=0 would plausibly mean)
+
+and reports max |M_pgo - M_candidate| / max |M_pgo| for each.  If a candidate matches (<= 1e-9) it writes
+`tests/golden/libpgo_operator_pin.npz` (COO triplets of libpgo's GTLTLG and G + the winning candidate's name),
+which `tests/test_oracle.py::test_libpgo_pin_if_present` then checks on every run -- from that commit on the
+operator is pinned to reference-held evidence.  If none matches, the dumped matrices still allow
+`TetSpheres(..., operator=L)` / `tsamd_create_with_operator` to run with whatever operator is inferred.
+
+Usage (needs libpgo built as in the reference's README.md:38; no GPU):
+
+    python tools/pin_L_with_pypgo.py [--veg /root/reference/tssplat_ext/a.veg] [--libpgo /path/to/libpgo_c.so]
+
+It tries, in order: the `pypgo` module (if it exports the two matrix constructors), then the C API via
+ctypes on `libpgo_c.so` (the library `find_package(pgo)` links, tssplat_ext/CMakeLists.txt:9,39).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import ctypes.util
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _coo_from_c_api(lib, handle, shape):
+    lib.pgo_sparse_matrix_get_num_entries.restype = C.c_int64
+    lib.pgo_sparse_matrix_get_num_entries.argtypes = [C.c_void_p]
+    nnz = int(lib.pgo_sparse_matrix_get_num_entries(handle))
+    rows = np.zeros(nnz, np.int32)
+    cols = np.zeros(nnz, np.int32)
+    vals = np.zeros(nnz, np.float64)
+    for fn, arr in ((lib.pgo_sparse_matrix_get_row_indices, rows), (lib.pgo_sparse_matrix_get_col_indices, cols),
+                    (lib.pgo_sparse_matrix_get_values, vals)):
+        fn.argtypes = [C.c_void_p, C.c_void_p]
+        fn(handle, arr.ctypes.data)
+    return sp.coo_matrix((vals, (rows, cols)), shape=shape).tocsr()
+
+
+def matrices_via_c_api(libpath, veg_path):
+    """GTLTLG and G exactly as TetSpheres::init obtains them (tet_spheres.cpp:140-159)."""
+    lib = C.CDLL(libpath)
+    lib.pgo_init()
+    lib.pgo_create_tetmeshgeo_from_file.restype = C.c_void_p
+    lib.pgo_create_tetmeshgeo_from_file.argtypes = [C.c_char_p]
+    geo = lib.pgo_create_tetmeshgeo_from_file(veg_path.encode())
+    if not geo:
+        raise RuntimeError(f"libpgo could not load {veg_path}")
+    lib.pgo_tetmeshgeo_get_num_vertices.argtypes = [C.c_void_p]
+    lib.pgo_tetmeshgeo_get_num_tets.argtypes = [C.c_void_p]
+    n = int(lib.pgo_tetmeshgeo_get_num_vertices(geo))
+    m = int(lib.pgo_tetmeshgeo_get_num_tets(geo))
+    lib.pgo_create_tet_biharmonic_gradient_matrix.restype = C.c_void_p
+    lib.pgo_create_tet_biharmonic_gradient_matrix.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.pgo_create_tet_gradient_matrix.restype = C.c_void_p
+    lib.pgo_create_tet_gradient_matrix.argtypes = [C.c_void_p]
+    M = _coo_from_c_api(lib, lib.pgo_create_tet_biharmonic_gradient_matrix(geo, 1, 0), (3 * n, 3 * n))   # :148
+    G = _coo_from_c_api(lib, lib.pgo_create_tet_gradient_matrix(geo), (9 * m, 3 * n))                     # :149
+    lib.pgo_destroy_tetmeshgeo.argtypes = [C.c_void_p]
+    lib.pgo_destroy_tetmeshgeo(geo)
+    return M, G, n, m
+
+
+def matrices_via_pypgo(veg_path):
+    import pypgo                                           # noqa: F401  (absent in the authoring container)
+    need = ("create_tet_biharmonic_gradient_matrix", "create_tet_gradient_matrix", "create_tetmeshgeo_from_file")
+    if not all(hasattr(pypgo, k) for k in need):
+        raise ImportError("this pypgo build does not export the matrix constructors; falling back to the C API")
+    geo = pypgo.create_tetmeshgeo_from_file(veg_path)
+    M = sp.csr_matrix(pypgo.create_tet_biharmonic_gradient_matrix(geo, 1, 0))
+    G = sp.csr_matrix(pypgo.create_tet_gradient_matrix(geo))
+    return M, G, M.shape[0] // 3, G.shape[0] // 9
+
+
+def vertex_neighbour_laplacian(tets):
+    m = tets.shape[0]
+    inc = sp.csr_matrix((np.ones(4 * m), (np.repeat(np.arange(m), 4), tets.ravel())), shape=(m, int(tets.max()) + 1))
+    A = (inc @ inc.T).tocsr()
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.data[:] = 1.0
+    return (sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A).tocsr()
+
+
+def compare(M_pgo, G_pgo, rest, tets, verbose=True):
+    """Diff libpgo's (GTLTLG, G) against the oracle's matrices for every candidate operator.
+    Returns (winner, max relative difference of the winner, max |G_oracle - G_pgo|)."""
+    from oracle import tet_energy_oracle as O
+    n, m = rest.shape[0], tets.shape[0]
+    say = print if verbose else (lambda *a, **k: None)
+    G = O.gradient_operator_sparse(rest, tets, n)
+    # libpgo's row order of vec(F) may be the transpose of ours (results do not depend on it)
+    perm = np.arange(9).reshape(3, 3).T.ravel()
+    Pm = sp.kron(sp.identity(m), sp.csr_matrix((np.ones(9), (np.arange(9), perm)), shape=(9, 9)), format="csr")
+    dG = min(abs(G - G_pgo).max(), abs(Pm @ G - G_pgo).max())
+    say(f"G: max |G_oracle - G_pgo| = {dG:.3e}  (max |G| = {abs(G_pgo).max():.3e})")
+    nbr = O.face_adjacency(tets)
+    cands = {"uniform": O.element_laplacian(nbr), "scaled": O.element_laplacian_scaled(nbr),
+             "vertex-neighbours": vertex_neighbour_laplacian(tets)}
+    best, best_err = None, np.inf
+    scale = abs(M_pgo).max()
+    for name, L in cands.items():
+        LG = (sp.kron(L, sp.identity(9), format="csr") @ G).tocsr()
+        Mc = (LG.T @ LG).tocsr()
+        err = abs(Mc - M_pgo).max() / scale
+        # a global constant factor would also be a match worth knowing about
+        k = (Mc.multiply(M_pgo)).sum() / max((Mc.multiply(Mc)).sum(), 1e-300)
+        err_k = abs(k * Mc - M_pgo).max() / scale
+        say(f"candidate {name:18s}: max rel diff {err:.3e}   (best global factor {k:.6g}: {err_k:.3e})")
+        if err < best_err:
+            best, best_err = name, err
+    return best, best_err, dG
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--veg", default="/root/reference/tssplat_ext/a.veg")
+    ap.add_argument("--libpgo", default=None, help="path of libpgo_c.so (default: search LD_LIBRARY_PATH)")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "libpgo_operator_pin.npz"))
+    args = ap.parse_args()
+    from tssplat_amd import scenes
+
+    try:
+        M_pgo, G_pgo, n, m = matrices_via_pypgo(args.veg)
+        how = "pypgo"
+    except Exception as e_py:                              # noqa: BLE001
+        libpath = args.libpgo or ctypes.util.find_library("pgo_c")
+        if not libpath:
+            raise SystemExit(f"neither pypgo ({e_py}) nor libpgo_c.so is available here; build libpgo as the reference's "
+                             "README.md:38 says, then pass --libpgo /path/to/libpgo_c.so")
+        M_pgo, G_pgo, n, m = matrices_via_c_api(libpath, args.veg)
+        how = f"C API ({libpath})"
+    rest, tets = scenes.read_veg(args.veg)
+    assert rest.shape[0] == n and tets.shape[0] == m, "mesh sizes disagree with libpgo"
+    print(f"libpgo via {how}: n={n} m={m} nnz(GTLTLG)={M_pgo.nnz} nnz(G)={G_pgo.nnz}")
+
+    best, best_err, dG = compare(M_pgo, G_pgo, rest, tets)
+    if best_err <= 1e-9:
+        Mc, Gc = M_pgo.tocoo(), G_pgo.tocoo()
+        np.savez_compressed(args.out, winner=best, mesh=os.path.basename(args.veg), n=n, m=m,
+                            M_row=Mc.row.astype(np.int32), M_col=Mc.col.astype(np.int32), M_val=Mc.data,
+                            G_row=Gc.row.astype(np.int32), G_col=Gc.col.astype(np.int32), G_val=Gc.data)
+        print(f"PINNED: libpgo's operator is the '{best}' candidate (max rel diff {best_err:.1e}); wrote {args.out}\n"
+              "commit that file: tests/test_oracle.py::test_libpgo_pin_if_present checks it from now on")
+    else:
+        print(f"NO candidate matches (best: {best}, {best_err:.3e}).  The assumption of this repo is wrong for this libpgo; "
+              "use TetSpheres(..., operator=L) / tsamd_create_with_operator with the operator inferred from the dump.")
+        sys.exit(2)
+
+
+if __name__ == "__main__":
+    main()
