@@ -3,28 +3,42 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one energy forward + backward over one batch of synthetic
-tet-spheres, through the reference's operator surface
-(``SmoothnessBarrierEnergy`` -> ``SmoothnessBarrierFunc`` -> ``tet_spheres_ext``).
-Metric (BASELINE.json): tetrahedra/sec, whole job, inputs resident in HBM.
+One "step" = one energy forward + backward (energy and full gradient) over one batch of synthetic
+tet-spheres.  Metric (BASELINE.json): tetrahedra/sec, whole job, inputs resident in HBM.
 
-Workload at N=1: the scene BASELINE.json quotes the metric on, the
-512-sphere / ~21 M-tet scene (512 x kuhn_ball(19)); it fits one
-GPU (1.6 GB of plan data).  N>1: weak scaling -- every rank owns its own 512
-spheres (tet-spheres share no vertices, so the path shards with no data-path
-collective; the only exchange is the all-reduce of the scalar energy, issued
-every step).  ``--scaling strong`` instead splits the 512 spheres over ranks.
+Workload: the scene BASELINE.json quotes the metric on, 512 tet-spheres x kuhn_ball(19) = 21 070 848 tets
+(SURVEY.md 8(d)); it fits one GPU (1.5 GB of plan data).  N > 1 is STRONG scaling by default -- the same 512
+spheres split over the ranks by whole spheres (north_star: >= 6x at 8 GPUs on this scene); `--scaling weak`
+gives every rank its own 512.  Tet-spheres share no vertices, so there is no data-path collective; the path's
+only exchange, the all-reduce of the scalar energy, is issued every step and its result is checked against the
+sum of the rank energies.
 
-Rank 0 prints ONE JSON line; extra keys: ``roofline`` (tile kernel, HIP events
-on the launch stream, algorithmic bytes 68 m + 24 n per evaluation) and, at
-N=1, ``cpu_baseline`` (the reference formulation in plain PyTorch on the host
-cores, on a bounded sample).
+Launch: one process per GPU.  Under `torchrun` / `python -m torch.distributed.run` the ranks come from the
+environment; a bare `python bench.py --gpus N` with N > 1 spawns the N ranks itself (127.0.0.1 rendezvous).
+
+How a step is issued (`--launch`): `graph` replays a HIP graph of the fused evaluation
+(tssplat_amd.energies.GraphedSmoothnessBarrier: same kernels, no per-step Python/autograd work) -- 5x faster on
+launch-bound batches (64-256 spheres of ~3 k tets: 16-31 us against 88 us per step); `eager` goes through
+`SmoothnessBarrierEnergy` + `backward()` (torch.autograd) like the reference trainer -- 1.5 % faster on the
+21 M-tet scene, where a replay cannot be queued behind its predecessor the way eager launches are.  `auto`
+(default) times a few steps of each during setup and keeps the faster; both are reported at N = 1.
+
+Setup ends with a pre-heat: ~40 back-to-back evaluations, outside every count, straight into the W warm-up steps.
+After the idle seconds of plan building the GPU needs ~25 ms of continuous work to reach its steady clocks
+(measured: 0.618 -> 0.565 -> 0.550 ms per step over the first three 20-step windows after idle); the driver's
+`--warmup 5 --steps 20` would otherwise time the ramp.
+
+Rank 0 prints ONE JSON line; extra keys: `roofline` (tile kernel, HIP events on the launch stream, algorithmic
+bytes 68 m + 24 n per evaluation) and, at N = 1, `cpu_baseline` (the reference formulation in plain PyTorch on
+the host cores, on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -39,16 +53,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--scene", default="kuhn19", help="kuhnK | cone (per-sphere template)")
+    p.add_argument("--scene", default="kuhn19", help="kuhnK | cone | delaunayN (per-sphere template)")
     p.add_argument("--spheres", type=int, default=512, help="spheres per job (strong) / per rank (weak)")
     p.add_argument("--sigma", type=float, default=0.02, help="deformation noise, fraction of sphere radius")
     p.add_argument("--order", type=int, default=2)
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    p.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
+                   help="auto = strong (the fixed 512-sphere scene split over the ranks)")
+    p.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                   help="auto = whichever of the two is faster on this batch (measured during setup)")
     p.add_argument("--max-threads", type=int, default=0)
     p.add_argument("--lds-budget", type=int, default=0)
     p.add_argument("--target-owned", type=int, default=0)
@@ -58,7 +75,10 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (bring-up on a 1-GPU box)")
     p.add_argument("--all-ranks-on-device0", action="store_true",
                    help="bring-up only: every rank uses cuda:0 (needs --dist-backend gloo)")
-    return p.parse_args()
+    p.add_argument("--dry-run", action="store_true",
+                   help="no GPU work: exercise rank launch, process group, energy all-reduce check and the JSON line "
+                        "(CPU test of the N > 1 plumbing, gloo)")
+    return p.parse_args(argv)
 
 
 def cpu_baseline(args, torch, scenes):
@@ -112,50 +132,127 @@ def cpu_baseline(args, torch, scenes):
     }
 
 
-def main():
-    args = parse()
-    import numpy as np
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _spawned_rank(rank: int, argv: list, world: int, port: int) -> None:
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    run_rank(parse(argv))
+
+
+def launch(argv=None) -> None:
+    """Entry point: run this rank, or -- `--gpus N > 1` without a launcher's environment -- spawn the N ranks."""
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(list(sys.argv[1:] if argv is None else argv), args.gpus, _free_port()),
+                 nprocs=args.gpus, join=True)
+        return
+    run_rank(args)
+
+
+def run_rank(args) -> None:
+    # stdout carries exactly one JSON line: everything else this process or its libraries print (the module's
+    # "initializing", Gloo's connection banner, ...) goes to stderr, at file-descriptor level
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        _run_rank(args, stdout_fd)
+    finally:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        os.close(stdout_fd)
+
+
+def _emit(stdout_fd: int, record: dict) -> None:
+    os.write(stdout_fd, (json.dumps(record) + "\n").encode())
+
+
+def _run_rank(args, stdout_fd: int) -> None:
     import torch
     import torch.distributed as dist
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):     # the module prints "initializing" like the reference does
-        from tssplat_amd import scenes
-        from tssplat_amd.energies import SmoothnessBarrierEnergy
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
-    if not torch.cuda.is_available():
+    scaling = "strong" if args.scaling == "auto" else args.scaling
+    if world == 1:
+        scaling = "weak" if args.scaling == "weak" else "strong"    # identical at one rank; keep the label honest
+    use_gpu = not args.dry_run
+    if use_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the tssplat_amd hot path has no CPU fallback")
     if args.all_ranks_on_device0:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
+        backend = "gloo" if args.dry_run else args.dist_backend
+        if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=args.dist_backend)
+            dist.init_process_group(backend=backend)
 
-    # ---- the batch this rank owns ----
-    if args.scaling == "weak":
-        my_spheres = args.spheres
-        seed = 1000 * rank
+    with contextlib.redirect_stdout(sys.stderr):     # the module prints "initializing" like the reference does
+        from tssplat_amd import scenes
+        from tssplat_amd.sharding import partition_spheres
+
+    # ---- the spheres this rank owns (whole spheres, contiguous, balanced on tet count) ----
+    if scaling == "weak":
+        my_spheres, total_spheres, seed = args.spheres, args.spheres * world, 1000 * rank
+        sc = scenes.make_scene(args.scene, my_spheres, seed=seed) if use_gpu else None
     else:
-        lo = args.spheres * rank // world
-        hi = args.spheres * (rank + 1) // world
-        my_spheres = hi - lo
-        seed = 1000 * rank
-    total_spheres = my_spheres * world if args.scaling == "weak" else args.spheres
-    t0 = time.time()
-    sc = scenes.make_scene(args.scene, my_spheres, seed=seed)
-    t_scene = time.time() - t0
+        total_spheres = args.spheres
+        if use_gpu:
+            full = scenes.make_scene(args.scene, total_spheres, seed=0)
+            lo, hi = partition_spheres(list(map(int, (full.sphere_tet_offsets[1:] - full.sphere_tet_offsets[:-1]))), world)[rank]
+            sc = full.slice_spheres(lo, hi)
+            del full
+        else:
+            lo, hi = partition_spheres([1] * total_spheres, world)[rank]
+            sc = None
+        my_spheres, seed = hi - lo, 0
+    c1_base = 2e-4 / total_spheres                   # geometry/tetmesh_geometry.py:242-243
+
+    if args.dry_run:
+        # plumbing only: a fake local energy, the real collective and check, fake timing
+        e_local = torch.tensor([float(my_spheres)])
+        red = e_local.clone()
+        work = dist.all_reduce(red, async_op=True) if world > 1 else None
+        if work is not None:
+            work.wait()
+        parts = [torch.zeros(1) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(parts, e_local)
+        else:
+            parts = [e_local]
+        assert abs(float(red) - sum(float(p) for p in parts)) <= 1e-6 * abs(float(red)), "all-reduced energy != sum of rank energies"
+        assert abs(float(red) - total_spheres) < 1e-6
+        if rank == 0:
+            _emit(stdout_fd, {"metric": "tetrahedra/sec (energy fwd+bwd)", "value": 0.0, "unit": "tets/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 0.0, "higher_is_better": True,
+                              "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "dry-run",
+                              "config": {"workload": "dry run (no GPU work)", "spheres_total": total_spheres,
+                                         "energy_allreduce_checked": True}})
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    with contextlib.redirect_stdout(sys.stderr):
+        from tssplat_amd.energies import GraphedSmoothnessBarrier, SmoothnessBarrierEnergy
 
     class Flags:
-        smooth_eng_coeff = 2e-4 / total_spheres     # geometry/tetmesh_geometry.py:242-243
+        smooth_eng_coeff = c1_base
         barrier_coeff = 2e-4
         increase_order_iter = 1000 if args.order == 2 else -1
 
@@ -166,22 +263,62 @@ def main():
     t_plan = time.time() - t0
     info = energy.tet_sp.plan_info()
     if rank == 0:
-        log(f"scene {my_spheres} x {args.scene}: n={sc.n_vertices} m={sc.n_tets} ({t_scene:.1f} s); "
-            f"plan {t_plan:.1f} s: {info}")
+        log(f"rank 0: {my_spheres} x {args.scene}: n={sc.n_vertices} m={sc.n_tets}; plan {t_plan:.1f} s: {info}")
     x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, args.sigma, seed=seed + 1)).to(dev))
     m_local, n_local = sc.n_tets, sc.n_vertices
     del sc
 
     it = 10
     c1, c2 = energy.coeff_scheduler(it)
-    e_sum = torch.zeros((), device=dev)
+    from tssplat_amd import _capi
+    lib = _capi.load()
+    g_raw = torch.empty_like(x)
+    e_raw = torch.empty((), device=dev)
+    stream0 = torch.cuda.current_stream(dev).cuda_stream
+    h = energy.tet_sp._handle()
 
-    def step():
+    def raw():
+        _capi.check(lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, args.order, stream0, e_raw.data_ptr(), g_raw.data_ptr()))
+
+    def preheat(ms=30.0):
+        """Continuous GPU work (no host sync inside) so that what follows starts at steady clocks."""
+        raw()
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        raw()
+        torch.cuda.synchronize(dev)
+        one = max(time.perf_counter() - t, 1e-6)
+        for _ in range(int(min(max(ms * 1e-3 / one, 40), 4000))):
+            raw()
+
+    graphed = None
+    if args.launch in ("auto", "graph"):
+        try:
+            graphed = GraphedSmoothnessBarrier(energy, x)
+            graphed.step(it)
+            torch.cuda.synchronize(dev)
+        except Exception as exc:                       # noqa: BLE001  (a runtime that cannot capture: run eagerly, say so)
+            log(f"HIP graph capture failed ({exc!r}); using --launch eager")
+            graphed = None
+
+    pending = []
+
+    def step_eager():
         x.grad = None
         e = energy(x, it, c1, c2)          # fused energy+gradient pass, finish kernel
         e.backward()                        # grad_output scale
-        if world > 1:                       # the path's only exchange: the scalar energy
-            dist.all_reduce(e.detach(), op=dist.ReduceOp.SUM, async_op=True)
+        return e.detach()
+
+    def step_graph():
+        return graphed.step(it)[0]
+
+    def step(fn):
+        e = fn()
+        if world > 1:                       # the path's only exchange: the scalar energy (never on the gradient's path)
+            red = e.clone().reshape(1)
+            pending.append((red, dist.all_reduce(red, op=dist.ReduceOp.SUM, async_op=True)))
+            if len(pending) > 4:
+                pending.pop(0)[1].wait()
         return e
 
     def fence():
@@ -190,24 +327,60 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        e = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    e_val = float(e.detach())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            step(fn)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e = step(fn)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        return el, e
 
-    # ---- roofline leg: the tile kernel alone, HIP events on the launch stream ----
+    launch_mode = args.launch if graphed is not None else "eager"
+    probe = {}
+    if launch_mode == "auto":                          # a few steps of each, after a pre-heat; ranks agree on rank 0's choice
+        for name, fn in (("graph", step_graph), ("eager", step_eager)):
+            preheat()
+            probe[name] = timed(fn, 10, 3)[0] / 10
+        pick = torch.tensor([0 if probe["graph"] <= probe["eager"] else 1], device=dev)
+        if world > 1:
+            dist.broadcast(pick, src=0)
+        launch_mode = "graph" if int(pick.item()) == 0 else "eager"
+    main_fn = step_graph if launch_mode == "graph" else step_eager
+    preheat()
+    elapsed, e_last = timed(main_fn, args.steps, args.warmup)
+    e_val = float(e_last)
+    # the collective's result = sum of the rank energies (checked, not just issued)
+    e_global = e_val
+    if world > 1:
+        for red, work in pending:
+            work.wait()
+        e_global = float(pending[-1][0])
+        parts = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(parts, e_last.clone().reshape(1))
+        e_sum = sum(float(p) for p in parts)
+        assert abs(e_global - e_sum) <= 1e-5 * abs(e_sum) + 1e-30, f"all-reduced energy {e_global} != sum of rank energies {e_sum}"
+    pending.clear()
+
+    other = None
+    if world == 1:                                     # the other launch mode, for the record
+        other_fn = step_eager if launch_mode == "graph" else (step_graph if graphed is not None else None)
+        if other_fn is not None:
+            preheat()
+            other = timed(other_fn, args.steps, min(args.warmup, 5))[0]
+
+    # ---- roofline leg: the tile kernel alone, HIP events on the launch stream (raw C-ABI evaluations) ----
+    preheat()
+    torch.cuda.synchronize(dev)
     energy.tet_sp.set_timing(True)
     for _ in range(args.steps):
-        step()
+        raw()
     torch.cuda.synchronize(dev)
     tile_ms, finish_ms, n_eval = energy.tet_sp.get_timing()
     energy.tet_sp.set_timing(False)
@@ -223,30 +396,19 @@ def main():
             key = f"{args.scene}x{my_spheres}"
             if key in rec:
                 traffic = rec[key]["hbm_bytes_per_launch"]
-        except Exception:
+        except Exception:                              # noqa: BLE001
             traffic = None
-
-    # ---- raw C-ABI rate (no autograd / Python operator overhead between launches) ----
-    from tssplat_amd import _capi
-    lib = _capi.load()
-    g = torch.empty_like(x)
-    ebuf = torch.empty((), device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    h = energy.tet_sp._handle()
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        _capi.check(lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, args.order, stream,
-                                               ebuf.data_ptr(), g.data_ptr()))
+        raw()
     torch.cuda.synchronize(dev)
     raw_elapsed = time.perf_counter() - t1
 
-    total_tets = m_local * world if args.scaling == "weak" else None
-    if args.scaling == "strong":
-        mt = torch.tensor([m_local], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(mt)
-        total_tets = int(mt.item())
+    mt = torch.tensor([m_local], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(mt)
+    total_tets = int(mt.item())
     value = total_tets * args.steps / elapsed
 
     out = None
@@ -260,22 +422,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{total_spheres} tet-spheres x {args.scene} ({total_tets} tets total, "
-                            f"{m_local} tets / {n_local} vertices per GPU), sigma={args.sigma}, order={args.order}, "
-                            f"energy+gradient through SmoothnessBarrierEnergy (autograd fwd+bwd)",
-                "spheres_per_gpu": my_spheres,
-                "tets_per_gpu": m_local,
-                "vertices_per_gpu": n_local,
-                "tiles_per_gpu": info["n_tiles"],
+                            f"{m_local} tets / {n_local} vertices on rank 0), sigma={args.sigma}, order={args.order}, "
+                            f"energy + full gradient per step",
+                "launch": ("HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier)" if launch_mode == "graph"
+                           else "eager: SmoothnessBarrierEnergy + backward() through torch.autograd"),
+                "spheres_rank0": my_spheres,
+                "tets_rank0": m_local,
+                "vertices_rank0": n_local,
+                "tiles_rank0": info["n_tiles"],
                 "slots_per_tet": info["total_slots"] / max(m_local, 1),
                 "block_threads": info["block_threads"],
                 "lds_bytes": info["lds_bytes"],
-                "parallelism": f"spheres sharded over {world} GPU(s), scalar energy all-reduce only",
+                "parallelism": f"whole spheres sharded over {world} GPU(s); one scalar-energy all-reduce per step, "
+                               f"result checked against the sum of rank energies",
             },
             "roofline": {
                 "bound": "hbm",
@@ -290,17 +455,20 @@ def main():
                 "finish_kernel_ms": finish_ms,
             },
             "raw_c_abi_tets_per_s": m_local * args.steps / raw_elapsed,
-            "energy": e_val,
+            "energy": e_global,
             "plan_build_s": t_plan,
         }
+        if other is not None:
+            key = "eager_autograd_ms_per_step" if launch_mode == "graph" else "graph_replay_ms_per_step"
+            out[key] = 1e3 * other / args.steps
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, torch, scenes)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(stdout_fd, out)
 
 
 if __name__ == "__main__":
-    main()
+    launch()

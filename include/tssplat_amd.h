@@ -154,6 +154,15 @@ int tsamd_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_de
 /* One pass producing both; energy_dev may be NULL. */
 int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, float c1,
                            float c2, int order, void *stream, float *energy_dev, float *grad_dev);
+/*
+ * The same evaluation with the two coefficients read ON THE DEVICE: coef_dev = {c1, c2} (2 floats).  The
+ * reference's schedule changes c1 and c2 every iteration (energies/smooth_barrier.py:47-58); with the
+ * coefficients in device memory a HIP graph captured once replays across iterations (the caller updates
+ * coef_dev, e.g. with a captured copy from pinned host memory).  energy_dev or grad_dev may be NULL (not both).
+ * No reference twin: the reference launches ~10 library calls per evaluation from the host every time.
+ */
+int tsamd_evaluate_dev_coef(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, const float *coef_dev,
+                            int order, void *stream, float *energy_dev, float *grad_dev);
 /* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 

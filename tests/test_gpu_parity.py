@@ -465,3 +465,33 @@ def test_reference_spelling_of_the_autograd_function(ext):
             assert x.grad.shape == x.shape and x.grad.device == x.device
     finally:
         tet_spheres_ext.CPU_ENERGY = prev
+
+
+def test_graph_replay_equals_eager(ext):
+    """GraphedSmoothnessBarrier (HIP-graph replay, coefficients read on the device) against the eager autograd route
+    over the reference's schedule: changing coefficients, the order switch at increase_order_iter, in-place updates
+    of the parameter between replays.  Same kernels on the same inputs: bitwise equal."""
+    from tssplat_amd import scenes
+    from tssplat_amd.energies import SmoothnessBarrierEnergy, GraphedSmoothnessBarrier
+
+    class Flags:
+        smooth_eng_coeff = 2e-4 / 6
+        barrier_coeff = 2e-4
+        increase_order_iter = 1000
+
+    sc = scenes.make_scene("kuhn8", 6)
+    mod = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, 0.3)).cuda())
+    graphed = GraphedSmoothnessBarrier(mod, x, grad_scale=0.75)
+    for it in (0, 1, 600, 600, 1000, 1001, 1500, 3):
+        with torch.no_grad():
+            x.add_(0.001 * torch.randn_like(x))                      # same storage, new values
+        e_g, g_g = graphed.step(it)
+        e_g, g_g = e_g.clone(), g_g.clone()
+        x.grad = None
+        c1, c2 = mod.coeff_scheduler(it)
+        e = mod(x, it, c1, c2)
+        (0.75 * e).backward()
+        assert float(e_g) == float(e.detach()), (it, float(e_g), float(e.detach()))
+        assert torch.equal(g_g, x.grad), it
+    assert sorted(graphed._graphs) == [2, 4]

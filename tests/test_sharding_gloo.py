@@ -153,3 +153,34 @@ def test_rejects_spheres_that_share_vertices():
     bad[0, 0] = vo[-1] - 1        # first sphere now references a vertex of the last one
     with pytest.raises(ValueError):
         ShardedSmoothnessBarrierEnergy(rest, bad, _Flags, vo, to, rank=0, world_size=2, local_factory=_OracleEnergy)
+
+
+def test_bench_spawns_its_own_ranks(capfd):
+    """`python bench.py --gpus 2` with no launcher environment spawns the two ranks itself; `--dry-run` runs the rank
+    launch, the gloo process group, the per-step energy all-reduce with its sum-of-ranks check and the JSON line
+    without touching a GPU (the driver launches N > 1 through torch.distributed.run; this is the bare-python route)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--spheres", "7",
+                          "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # exactly one JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "strong" and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["config"]["energy_allreduce_checked"] and rec["config"]["spheres_total"] == 7
+    # under a launcher's environment the same file runs as ONE rank of the job (no nested spawn)
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run", "--spheres", "3"],
+                         capture_output=True, text=True, env=env1, timeout=300)
+    assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["n_gpus"] == 1
+
+
+def test_scene_slices_are_self_contained():
+    sc = scenes.make_scene("kuhn3", 5)
+    part = sc.slice_spheres(1, 4)
+    assert part.n_spheres == 3 and part.tets.min() == 0 and part.tets.max() == part.n_vertices - 1
+    assert np.array_equal(part.rest, sc.rest[sc.sphere_vertex_offsets[1]:sc.sphere_vertex_offsets[4]])

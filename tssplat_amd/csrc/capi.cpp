@@ -197,7 +197,7 @@ int check_eval(tsamd_handle *h, const float *x)
 }
 
 int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, float c2, int order, void *stream,
-             float *energy, float *grad)
+             float *energy, float *grad, const float *coef = nullptr)
 {
     int rc = check_eval(h, x);
     if (rc) return rc;
@@ -226,6 +226,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.grad_out = grad_out;
     a.c1 = c1;
     a.c2 = c2;
+    a.coef = coef;
     a.order = order;
     a.grad = grad;
     a.stage = h->d_stage;
@@ -363,6 +364,15 @@ int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *gra
     if (!grad_dev && h && h->plan.n > 0) return fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_dev is null");
     return evaluate(h, x_dev, grad_out_dev, c1, c2, order, stream, energy_dev ? energy_dev : (h ? h->d_energy_scratch : nullptr),
                     grad_dev);
+}
+
+int tsamd_evaluate_dev_coef(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, const float *coef_dev,
+                            int order, void *stream, float *energy_dev, float *grad_dev)
+{
+    if (!coef_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "coef_dev is null");
+    if (!energy_dev && !grad_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "nothing to compute: energy_dev and grad_dev are both null");
+    return evaluate(h, x_dev, grad_out_dev, 0.f, 0.f, order, stream,
+                    energy_dev ? energy_dev : (grad_dev && h ? h->d_energy_scratch : nullptr), grad_dev, coef_dev);
 }
 
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)

@@ -27,6 +27,7 @@ struct EvalArgs {
     const float *x;
     const float *grad_out;  // device scalar or nullptr
     float c1, c2;
+    const float *coef = nullptr;  // device (c1, c2) overriding the two values above when non-null
     int order;
     float *grad;            // nullptr = energy only
     float *stage;           // [n_stage, 3]

@@ -171,6 +171,7 @@ struct KernelArgs {
     float *stage;
     double *partials;
     float c1, c2;
+    const float *coef;  // optional: (c1, c2) read on the device instead (graph replays with changing coefficients)
     int order;
     int n_tiles;
     int tiles_per_xcd;
@@ -221,6 +222,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #endif
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
+    const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
     const auto g_blob = as_global(a.blob);
     const auto g_gvid = as_global(a.gvid);
     const auto g_sdst = as_global(a.sdst);
@@ -303,7 +305,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             }
             if (w0 & kOwnedBit) {
                 e_b += pen;
-                scal[p] = a.c2 * dpen;
+                scal[p] = k_c2 * dpen;
             }
             store_slot(smem, uint32_t(p * nq + tid), F);
             SLOT_FENCE();
@@ -402,8 +404,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 } else {
                     q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
                 }
-                q.p01 *= a.c1; q.p23 *= a.c1; q.p45 *= a.c1; q.p67 *= a.c1;
-                q.p8 *= a.c1;
+                q.p01 *= k_c1; q.p23 *= k_c1; q.p45 *= k_c1; q.p67 *= k_c1;
+                q.p8 *= k_c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
                     if (!kReload) {  // rare path: fetch the vertex offsets again instead of pinning them
@@ -570,6 +572,7 @@ __device__ __forceinline__ void tile_walk(const KernelArgs &a, int tile, const i
     typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
     typedef float VF __attribute__((ext_vector_type(SPT)));
     const int tid0 = threadIdx.x, nthr = blockDim.x;
+    const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
     const auto g_blob = as_global(a.blob);
     const auto g_gvid = as_global(a.gvid);
     const auto g_sdst = as_global(a.sdst);
@@ -647,7 +650,7 @@ __device__ __forceinline__ void tile_walk(const KernelArgs &a, int tile, const i
                 }
                 if (w0 & kOwnedBit) {
                     e_b += pen;
-                    scal[p] = a.c2 * dpen;
+                    scal[p] = k_c2 * dpen;
                 }
                 store_slot(smem, uint32_t(p * nq + tid), F);
                 SLOT_FENCE();
@@ -715,8 +718,8 @@ __device__ __forceinline__ void tile_walk(const KernelArgs &a, int tile, const i
                 uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
                 const uint32_t so = uint32_t(p * nq + tid);
                 Mat9 q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
-                q.p01 *= a.c1; q.p23 *= a.c1; q.p45 *= a.c1; q.p67 *= a.c1;
-                q.p8 *= a.c1;
+                q.p01 *= k_c1; q.p23 *= k_c1; q.p45 *= k_c1; q.p67 *= k_c1;
+                q.p8 *= k_c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
@@ -900,6 +903,7 @@ struct FinishArgs {
     const double *partials;
     int64_t n_tiles;
     float c1, c2;
+    const float *coef;  // optional device (c1, c2), see KernelArgs
     float *energy;
     double *terms;
 };
@@ -942,7 +946,8 @@ __device__ __forceinline__ void energy_reduce(const FinishArgs &a, double *red)
     if (tid == 0) {
         a.terms[0] = red[0];
         a.terms[1] = red[T];
-        a.energy[0] = float(double(a.c1) * red[0] + double(a.c2) * red[T]);
+        const float c1 = a.coef ? a.coef[0] : a.c1, c2 = a.coef ? a.coef[1] : a.c2;
+        a.energy[0] = float(double(c1) * red[0] + double(c2) * red[T]);
     }
 }
 
@@ -1165,6 +1170,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.partials = e.partials;
         k.c1 = e.c1;
         k.c2 = e.c2;
+        k.coef = e.coef;
         k.order = e.order;
         k.n_tiles = int(e.n_tiles);
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
@@ -1218,6 +1224,7 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     f.n_tiles = e.n_tiles;
     f.c1 = e.c1;
     f.c2 = e.c2;
+    f.coef = e.coef;
     f.energy = e.energy;
     f.terms = e.terms;
     if (f.n_finish > 0) {

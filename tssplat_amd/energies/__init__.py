@@ -1,1 +1,2 @@
 from .smooth_barrier import SmoothnessBarrierEnergy, SmoothnessBarrierFunc  # noqa: F401
+from .graphed import GraphedSmoothnessBarrier  # noqa: F401

@@ -53,6 +53,15 @@ class TetScene:
     def n_spheres(self) -> int:
         return int(self.radii.shape[0])
 
+    def slice_spheres(self, lo: int, hi: int) -> "TetScene":
+        """Spheres ``[lo, hi)`` as a scene of their own (vertex ids re-based): what one rank owns when the batch
+        is sharded by whole spheres."""
+        v0, v1 = int(self.sphere_vertex_offsets[lo]), int(self.sphere_vertex_offsets[hi])
+        t0, t1 = int(self.sphere_tet_offsets[lo]), int(self.sphere_tet_offsets[hi])
+        return TetScene(rest=self.rest[v0:v1], tets=(self.tets[t0:t1] - v0).astype(np.int32),
+                        sphere_vertex_offsets=self.sphere_vertex_offsets[lo:hi + 1] - v0,
+                        sphere_tet_offsets=self.sphere_tet_offsets[lo:hi + 1] - t0, radii=self.radii[lo:hi])
+
 
 def _orient_positive(verts: np.ndarray, tets: np.ndarray) -> np.ndarray:
     """Swap local vertices 1<->2 of negatively oriented tets so det(Dm) > 0."""
