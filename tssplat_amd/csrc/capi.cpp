@@ -57,7 +57,6 @@ struct tsamd_handle {
     // optional kernel timing (bench.py roofline leg)
     int dbg = 0;  // kernel ablation switches, tools/ablate.py only
     long long *d_clk = nullptr;  // 16 clock stamps per tile (ablation builds)
-    int walk_blocks = 0;  // resident workgroups of the fused kernel: 2 per CU (0 = one workgroup per tile)
     bool timing = false;
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
@@ -112,12 +111,6 @@ int to_device(tsamd_handle *h, int device)
     TSAMD_HIP(g.enter(device));
     h->device = device;
     h->host_only = false;
-    {
-        const char *w = std::getenv("TSSPLAT_AMD_WALK");   // experiment switch: 1 = resident workgroups (default: one workgroup per tile)
-        h->walk_blocks = (w && w[0] == '1') ? 2 * prop.multiProcessorCount : 0;
-        const char *d = std::getenv("TSSPLAT_AMD_DBG");
-        if (d) h->dbg = std::atoi(d);
-    }
     const tsamd::Plan &P = h->plan;
     int rc;
     if ((rc = upload(h->d_tiles, P.tiles.data(), P.tiles.size(), h->device_bytes))) return rc;
@@ -216,10 +209,6 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.lds_bytes = h->plan.lds_bytes;
     a.spt = h->plan.spt;
     a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
-    a.walk_blocks = h->walk_blocks;
-    a.sa_max = ((h->plan.max_slots + 3) & ~3) + 4;
-    a.vp_max = (h->plan.max_verts + 3) & ~3;
-    a.lds_bytes_walk = 48 * a.sa_max + 16 * a.vp_max + 256;
     a.dbg = h->dbg;
     a.clk = h->d_clk;
     a.x = x;

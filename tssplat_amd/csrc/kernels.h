@@ -19,8 +19,6 @@ struct EvalArgs {
     int32_t block_threads, lds_bytes;
     int32_t spt = 4;        // slots per thread the plan was laid out for
     bool weighted = false;        // the plan carries an explicit element operator (22 planes per slot)
-    int32_t walk_blocks = 0;      // > 0: resident workgroups for the fused kernel (2 per CU)
-    int32_t sa_max = 0, vp_max = 0, lds_bytes_walk = 0;  // fixed LDS layout of the resident walk
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
     long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
     // per evaluation

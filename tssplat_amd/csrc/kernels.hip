@@ -62,7 +62,6 @@ __device__ __forceinline__ void cof3(const float *F, float *C)
 // cannot infer the address space of pointers read from KernelArgs and would emit flat_* loads, which share
 // the LDS counter (lgkmcnt): every LDS wait would then also wait for outstanding HBM loads.
 #define GLOBAL_AS __attribute__((address_space(1)))
-#define CONST_AS __attribute__((address_space(4)))
 template <class T>
 __device__ __forceinline__ GLOBAL_AS T *as_global(T *p)
 {
@@ -175,7 +174,6 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
-    int sa_max, vp_max;  // resident walk: fixed LDS layout for the largest tile of the plan
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
     long long *clk;  // ablation builds: 16 shader-clock stamps per tile (phase boundaries of thread 0)
 };
@@ -542,342 +540,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 }
 
 
-// Tile descriptor through the constant address space: uniform address + invariant memory = scalar loads.
-// (Through a plain pointer the compiler cannot prove inside the resident walk that no store of the kernel clobbers
-// the descriptor array, loads it with vector instructions and keeps its 12 dwords in VGPRs -- twice.)
-__device__ __forceinline__ TileDesc load_desc_uniform(const TileDesc *p)
-{
-    const CONST_AS v4u *q = (const CONST_AS v4u *)p;
-    const v4u w0 = q[0], w1 = q[1], w2 = q[2];
-    const uint32_t d[12] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w};
-    TileDesc t;
-    __builtin_memcpy(&t, d, sizeof(t));
-    return t;
-}
-
-// Resident workgroup walking tiles tile, tile + step, ... < tile_end (fused energy + gradient only).
-// The stream phase of a tile (13 plane loads + the vertex id -> position chain) is ~25 % of its time and
-// nothing else of that workgroup runs meanwhile.  Here it disappears behind the previous tile's tail:
-// the plane registers (lv / nb / Dm^-1, 26 VGPRs at 2 slots per lane) are dead once pass 3 has produced
-// the vertex forces, so the NEXT tile's planes are loaded into those very registers right there and land
-// while force store, vertex gather and energy reduction run -- no extra registers, no second LDS buffer.
-// The next tile's vertex ids are fetched one phase earlier (1 VGPR across pass 3), its positions right
-// after pass 3 (3 VGPRs) and written to xs once the last reader of the current positions is past the
-// barrier.  LDS layout is fixed for the walk (SA / VP = the plan's maxima).
-template <int SPT>
-__device__ __forceinline__ void tile_walk(const KernelArgs &a, int tile, const int tile_step, const int tile_end,
-                                          const int SA, const int VP)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
-    typedef float VF __attribute__((ext_vector_type(SPT)));
-    const int tid0 = threadIdx.x, nthr = blockDim.x;
-    const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
-    const auto g_blob = as_global(a.blob);
-    const auto g_gvid = as_global(a.gvid);
-    const auto g_sdst = as_global(a.sdst);
-    const auto g_x = as_global(a.x);
-    const auto g_grad = as_global(a.grad);
-    const auto g_stage = as_global(a.stage);
-    const auto g_partials = as_global(a.partials);
-    unsigned char *xs = smem + 48 * SA;
-    double *red = reinterpret_cast<double *>(xs + 16 * VP);
-    const float gscale = a.grad_out ? *as_global(a.grad_out) : 1.f;
-
-    TileDesc td = load_desc_uniform(a.tiles + tile);
-    VU q_lv01, q_lv23, q_nb01, q_nb23;
-    VF dm[9];
-    // ---- prologue: stream and stage the first tile (same order of loads as the one-tile kernel) ----
-    {
-        const int nq0 = td.s_pad / SPT;
-        const int lt = tid0 < nq0 ? tid0 : 0;
-        const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);
-        int32_t gv0 = g_gvid[td.vert_off + (tid0 < td.n_verts ? tid0 : 0)];
-        q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt);
-        q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt);
-        q_nb01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 2 * td.s_pad + SPT * lt);
-        q_nb23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 3 * td.s_pad + SPT * lt);
-#pragma unroll
-        for (int c = 0; c < 9; ++c) dm[c] = *reinterpret_cast<const GLOBAL_AS VF *>(pl + (4 + c) * td.s_pad + SPT * lt);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(gv0));
-        if (tid0 < td.n_verts) {
-            const size_t gv = size_t(gv0) * 3;
-            reinterpret_cast<float4 *>(xs)[tid0] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        }
-        for (int v = tid0 + nthr; v < td.n_verts; v += nthr) {
-            const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
-            reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        }
-    }
-
-    for (;;) {
-        // opaque copy of the lane id: keeps the compiler from hoisting every address derived from it out of the
-        // tile loop, where each one would pin a VGPR for the whole walk (measured: 29 spilled dwords)
-        int tid = tid0;
-        asm volatile("" : "+v"(tid));
-        const int next = tile + tile_step < tile_end ? tile + tile_step : -1;
-        const bool has_next = next >= 0;
-        TileDesc tdn = td;
-        if (has_next) tdn = load_desc_uniform(a.tiles + next);
-        const int nq = td.s_pad / SPT;
-        const uint32_t ZS = uint32_t(td.s_pad);
-        const bool active = tid < nq;
-        const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);
-        if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
-        __syncthreads();  // positions staged (by the prologue or by the previous tile's tail)
-
-        // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
-        float scal[SPT];
-#pragma unroll
-        for (int p = 0; p < SPT; ++p) scal[p] = 0.f;
-        float e_b = 0.f, e_s = 0.f;
-        if (active) {
-#pragma unroll
-            for (int p = 0; p < SPT; ++p) {
-                const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
-                float F[9];
-                slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
-                const float J = det3(F);
-                const float Jm = fmaxf(-J, 0.f);
-                float pen = 0.f, dpen = 0.f;
-                if (a.order == 2) {
-                    pen = Jm * Jm;
-                    dpen = -2.f * Jm;
-                } else if (a.order == 4) {
-                    pen = Jm * Jm * Jm * Jm;
-                    dpen = -4.f * Jm * Jm * Jm;
-                }
-                if (w0 & kOwnedBit) {
-                    e_b += pen;
-                    scal[p] = k_c2 * dpen;
-                }
-                store_slot(smem, uint32_t(p * nq + tid), F);
-                SLOT_FENCE();
-            }
-        }
-        __syncthreads();
-
-        // ---- pass 2: H = L F on owned slots, E_s = 1/2 |H|^2 ----
-        float H[SPT][9];
-#pragma unroll
-        for (int p = 0; p < SPT; ++p)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
-        if (active) {
-#pragma unroll
-            for (int p = 0; p < SPT; ++p) {
-                const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
-                if (n01 & kOwnedBit) {
-                    uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
-                    const uint32_t so = uint32_t(p * nq + tid);
-                    const Mat9 h = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
-                    v2f sq = h.p01 * h.p01;
-                    sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
-                    sq = __builtin_elementwise_fma(h.p45, h.p45, sq);
-                    sq = __builtin_elementwise_fma(h.p67, h.p67, sq);
-                    e_s += 0.5f * (sq.x + sq.y + h.p8 * h.p8);
-                    H[p][0] = h.p01.x; H[p][1] = h.p01.y; H[p][2] = h.p23.x; H[p][3] = h.p23.y;
-                    H[p][4] = h.p45.x; H[p][5] = h.p45.y; H[p][6] = h.p67.x; H[p][7] = h.p67.y;
-                    H[p][8] = h.p8;
-                }
-                SLOT_FENCE();
-            }
-        }
-        __syncthreads();
-
-        constexpr int kPre = 3;
-        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kPlanes * td.s_pad);
-        const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
-        const uint32_t pad16 = (ZS << 2) | 1u;
-        int pc0, pc1;
-        v2u pre[kPre];
-        if (active) {
-#pragma unroll
-            for (int p = 0; p < SPT; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
-        }
-        // issued one phase early (3 VGPRs across pass 3) so that nothing after pass 3 has to wait for a load before the
-        // next tile's prefetch can go out: the next tile's vertex id (one HBM latency ahead of its position loads)
-        // and this lane's incidence-list bounds (one latency ahead of the list chunks)
-        const bool vact = tid < 2 * td.n_verts;
-        const int vv = vact ? (tid >> 1) : 0;
-        int32_t gvn = g_gvid[tdn.vert_off + (tid < tdn.n_verts ? tid : 0)];
-        uint32_t o0 = inc_off[vv], o1 = inc_off[vv + 1];
-        __syncthreads();
-
-        // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T ----
-        float D[SPT][9];
-#pragma unroll
-        for (int p = 0; p < SPT; ++p)
-#pragma unroll
-            for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
-        if (active) {
-#pragma unroll
-            for (int p = 0; p < SPT; ++p) {
-                const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
-                uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
-                const uint32_t so = uint32_t(p * nq + tid);
-                Mat9 q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
-                q.p01 *= k_c1; q.p23 *= k_c1; q.p45 *= k_c1; q.p67 *= k_c1;
-                q.p8 *= k_c1;
-                float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
-                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
-                    float F[9], C[9];
-                    slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
-                    cof3(F, C);
-#pragma unroll
-                    for (int c = 0; c < 9; ++c) P[c] += scal[p] * C[c];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-                        D[p][3 * k + i] = P[3 * i + 0] * dm[3 * k + 0][p] + P[3 * i + 1] * dm[3 * k + 1][p] +
-                                          P[3 * i + 2] * dm[3 * k + 2][p];
-                SLOT_FENCE();
-            }
-        }
-        // ---- straight-line load section (no branches: the compiler can then count its waits instead of draining
-        // vmcnt to 0 in front of the first use, which would wait for the whole prefetch) ----
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(gvn), "+v"(o0), "+v"(o1));  // (keeps the address arithmetic on them from being hoisted up to the loads)
-        pc0 = int(o0) + (tid & 1);
-        pc1 = vact ? int(o1) : 0;
-        const bool excl = vv < td.n_excl;
-        const GLOBAL_AS int32_t *rowp = excl ? g_gvid + (td.vert_off + vv) : g_sdst + (td.stage_off + (vv - td.n_excl));
-        const int32_t dst_row = *rowp;
-#pragma unroll
-        for (int q = 0; q < kPre; ++q) {
-            const bool ok = pc0 + 2 * q < pc1;
-            const v2u w = inc[ok ? pc0 + 2 * q : 0];
-            pre[q] = ok ? w : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
-        }
-        // the next tile (the current one again after the last: harmless re-read that keeps this section branch-free):
-        // positions (3 VGPRs), then the planes into the plane registers, which are dead from here on
-        float nx, ny, nz;
-        {
-            const size_t gv = size_t(gvn) * 3;
-            nx = g_x[gv];
-            ny = g_x[gv + 1];
-            nz = g_x[gv + 2];
-            const int lt = tid < tdn.s_pad / SPT ? tid : 0;
-            const GLOBAL_AS uint32_t *pn = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + tdn.blob_off);
-            q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pn + 0 * tdn.s_pad + SPT * lt);
-            q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pn + 1 * tdn.s_pad + SPT * lt);
-            q_nb01 = *reinterpret_cast<const GLOBAL_AS VU *>(pn + 2 * tdn.s_pad + SPT * lt);
-            q_nb23 = *reinterpret_cast<const GLOBAL_AS VU *>(pn + 3 * tdn.s_pad + SPT * lt);
-#pragma unroll
-            for (int c = 0; c < 9; ++c) dm[c] = *reinterpret_cast<const GLOBAL_AS VF *>(pn + (4 + c) * tdn.s_pad + SPT * lt);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();  // all waves done with H and with the staged positions
-        if (active) {
-#pragma unroll
-            for (int p = 0; p < SPT; ++p) {
-                unsigned char *r = smem + uint32_t(p * nq + tid) * 48u;
-                const float *d = D[p];
-                *reinterpret_cast<v4f *>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
-                *reinterpret_cast<v4f *>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
-                *reinterpret_cast<v4f *>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
-            }
-        }
-        __syncthreads();
-
-        // ---- per-vertex gather of the incident tets' forces ----
-        for (int u = tid; u < 2 * td.n_verts; u += nthr) {
-            const int v = u >> 1;
-            float gx = 0.f, gy = 0.f, gz = 0.f;
-            auto gather4 = [&](const v2u w) {
-                const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float *f = reinterpret_cast<const float *>(smem + ent[q] * 12u);
-                    gx += f[0];
-                    gy += f[1];
-                    gz += f[2];
-                }
-            };
-            int32_t row = dst_row;
-            int c, c1;
-            if (u == tid) {
-                c = pc0;
-                c1 = pc1;
-#pragma unroll
-                for (int q = 0; q < kPre; ++q) {
-                    if (__builtin_amdgcn_ballot_w64(c < c1) == 0) break;
-                    gather4(pre[q]);
-                    c += 2;
-                }
-            } else {
-                c = inc_off[v] + (u & 1);
-                c1 = inc_off[v + 1];
-                row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
-            }
-            for (; c < c1; c += 2) gather4(inc[c]);
-            gx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gx), 0xB1, 0xf, 0xf, false));
-            gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xf, 0xf, false));
-            gz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0xB1, 0xf, 0xf, false));
-            if (u & 1) continue;
-            GLOBAL_AS float *dst = (v < td.n_excl ? g_grad : g_stage) + size_t(row) * 3;
-            const float sc = v < td.n_excl ? gscale : 1.f;
-            dst[0] = gx * sc;
-            dst[1] = gy * sc;
-            dst[2] = gz * sc;
-        }
-        // the next tile's positions: xs has had no reader since the barrier after pass 3
-        if (has_next) {
-            if (tid < tdn.n_verts) reinterpret_cast<float4 *>(xs)[tid] = make_float4(nx, ny, nz, 0.f);
-            for (int v = tid + nthr; v < tdn.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
-                const size_t gv = size_t(g_gvid[tdn.vert_off + v]) * 3;
-                reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-            }
-        }
-        // ---- deterministic block reduction of the two energy terms ----
-#pragma unroll
-        for (int off = kWave / 2; off > 0; off >>= 1) {
-            e_s += __shfl_down(e_s, off, kWave);
-            e_b += __shfl_down(e_b, off, kWave);
-        }
-        const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
-        if (lane == 0) {
-            red[2 * wave] = double(e_s);
-            red[2 * wave + 1] = double(e_b);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            double s = 0.0, b = 0.0;
-            for (int w = 0; w < nw; ++w) {
-                s += red[2 * w];
-                b += red[2 * w + 1];
-            }
-            g_partials[2 * size_t(tile)] = s;
-            g_partials[2 * size_t(tile) + 1] = b;
-        }
-        if (!has_next) break;
-        tile = next;
-        td = tdn;
-    }
-}
-
-// Persistent launch of the fused kernel: gridDim.x = 8 * (workgroups per XCD); workgroup b walks the tiles
-// xcd * tiles_per_xcd + jb, + step, ... of its XCD's contiguous run (step = workgroups per XCD).
-template <int BLOCK, int SPT, int WPE>
-__global__ __launch_bounds__(BLOCK, WPE) void tile_walk_kernel(const KernelArgs a)
-{
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int step = int(gridDim.x >> 3);
-    const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
-    const int tile = xcd * a.tiles_per_xcd + jb;
-    if (tile >= tile_end) return;
-    // experiment: de-phase the two workgroups of a CU (which pairs share a CU is not known: try both patterns)
-    if (((a.dbg & 512) && (jb & 1)) || ((a.dbg & 1024) && jb >= (step >> 1))) {
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-    }
-    tile_walk<SPT>(a, tile, step, tile_end, a.sa_max, a.vp_max);
-}
-
 template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
@@ -1131,7 +793,6 @@ hipError_t configure_kernels(int lds_bytes)
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>),
-                         reinterpret_cast<const void *>(&tile_walk_kernel<768, 2, 6>),
                          // explicit-operator builds (one more register-hungry stream: 128-VGPR launch bounds)
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, true>),
@@ -1183,8 +844,6 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(lds), stream, k)
         const size_t lds = size_t(e.lds_bytes);
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
-        k.sa_max = e.sa_max;
-        k.vp_max = e.vp_max;
         if (e.weighted) {
 #define TSAMD_LAUNCH_W(G, S) hipLaunchKernelGGL((tile_energy_kernel<G, 1024, S, 4, true>), grid, block, size_t(lds), stream, k)
             if (e.spt == 2) {
@@ -1193,10 +852,6 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
                 if (e.grad) TSAMD_LAUNCH_W(true, 4); else TSAMD_LAUNCH_W(false, 4);
             }
 #undef TSAMD_LAUNCH_W
-        } else if (e.grad && two_per_cu && e.walk_blocks > 0 && e.n_tiles > e.walk_blocks && e.lds_bytes_walk <= 80 * 1024) {
-            // resident workgroups (two per CU) walking their XCD's tiles with next-tile prefetch
-            hipLaunchKernelGGL((tile_walk_kernel<768, 2, 6>), dim3(unsigned(e.walk_blocks / 8 * 8)), block,
-                               size_t(e.lds_bytes_walk), stream, k);
         } else if (e.spt == 2 && two_per_cu) {
             if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
         } else if (e.spt == 2) {

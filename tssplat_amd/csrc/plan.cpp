@@ -10,10 +10,13 @@
 // plus 16-bit local vertex / neighbour indices.  Pure C++17, no HIP.
 #include "plan.h"
 
+#include "conflict_opt.h"
+
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -751,8 +754,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             // ---- LDS bank-conflict-aware neighbour order ----
             // A wave reads neighbour k of 16 lanes' tets with one ds_read_b128 per 16-lane group; two lanes
             // collide when their records share a 16-byte bank column, i.e. when the record indices agree
-            // mod 16 (48 B stride: column = 3 * idx mod 16).  The order of a tet's four neighbours is free,
-            // so within every lane group pick, step by step, neighbours with distinct residues.
+            // mod 16 (48 B stride: column = 3 * idx mod 16).  The order of a tet's four neighbours is free:
+            // every lane group gets a proper 4-edge-colouring of its lanes x columns read graph (conflict_opt.cpp).
             if (opt.conflict_aware) {
                 static const int kGroups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
                                                    {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
@@ -777,28 +780,10 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 ++nl;
                             }
                             uint32_t chosen[16][4];
-                            int from[16][4];   // chosen[li][step] was candidate from[li][step] (the weights follow)
-                            bool taken[16][4] = {};
-                            for (int step = 0; step < 4; ++step) {
-                                int64_t colrec[16];
-                                for (auto &c : colrec) c = -1;
-                                for (int li = 0; li < nl; ++li) {
-                                    int pick = -1;
-                                    for (int c = 0; c < 4 && pick < 0; ++c) {
-                                        if (taken[li][c]) continue;
-                                        const uint32_t r = cand[li][c] & 15u;
-                                        if (colrec[r] < 0 || colrec[r] == int64_t(cand[li][c])) pick = c;
-                                    }
-                                    if (pick < 0)
-                                        for (int c = 0; c < 4 && pick < 0; ++c)
-                                            if (!taken[li][c]) pick = c;
-                                    taken[li][pick] = true;
-                                    chosen[li][step] = cand[li][pick];
-                                    from[li][step] = pick;
-                                    const uint32_t r = cand[li][pick] & 15u;
-                                    if (colrec[r] < 0) colrec[r] = int64_t(cand[li][pick]);
-                                }
-                            }
+                            int from[16][4];   // chosen[li][step] is candidate from[li][step] (the weights follow)
+                            colour_group_reads(nl, cand, ZS, from);
+                            for (int li = 0; li < nl; ++li)
+                                for (int step = 0; step < 4; ++step) chosen[li][step] = cand[li][from[li][step]];
                             for (int li = 0; li < nl; ++li) {
                                 const int32_t sl = lane_slot[li];
                                 p2[sl] = (p2[sl] & ~(kSlotMask | (kSlotMask << 16))) | chosen[li][0] | (chosen[li][1] << 16);
