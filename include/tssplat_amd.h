@@ -179,8 +179,9 @@ int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_ker
  * Any nonzero value makes results WRONG; production code never calls this. */
 int tsamd_debug_set_ablation(tsamd_handle *h, int flags);
 /* Diagnostic only, meaningful in -DTSAMD_ABLATION builds: the first call arms 16 shader-clock
- * stamps per tile (phase boundaries seen by thread 0 of each workgroup), later calls copy the
- * stamps of the most recent evaluation to host_out (capacity >= 16 * n_tiles). */
+ * stamps per wave (phase boundaries seen by lane 0 of each of up to 16 waves of a workgroup), later calls
+ * copy the stamps of the most recent evaluation to host_out (capacity >= 256 * n_tiles,
+ * index (16 * tile + wave) * 16 + stamp). */
 int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capacity);
 
 /* out[i] = in[i] * (*scalar_dev); in == out allowed. */

@@ -470,7 +470,7 @@ def test_reference_spelling_of_the_autograd_function(ext):
 def test_graph_replay_equals_eager(ext):
     """GraphedSmoothnessBarrier (HIP-graph replay, coefficients read on the device) against the eager autograd route
     over the reference's schedule: changing coefficients, the order switch at increase_order_iter, in-place updates
-    of the parameter between replays.  Same kernels on the same inputs: bitwise equal."""
+    of the parameter between replays.  Same kernels on the same inputs: the energy is bitwise equal."""
     from tssplat_amd import scenes
     from tssplat_amd.energies import SmoothnessBarrierEnergy, GraphedSmoothnessBarrier
 
@@ -493,5 +493,7 @@ def test_graph_replay_equals_eager(ext):
         e = mod(x, it, c1, c2)
         (0.75 * e).backward()
         assert float(e_g) == float(e.detach()), (it, float(e_g), float(e.detach()))
-        assert torch.equal(g_g, x.grad), it
+        # (the gradient is not bitwise equal: the replay applies grad_output inside the kernel, as one factor c1 * 0.75,
+        # the eager route scales by c1 in the kernel and by 0.75 in tsamd_scale)
+        assert torch.allclose(g_g, x.grad, rtol=3e-7, atol=0), it
     assert sorted(graphed._graphs) == [2, 4]

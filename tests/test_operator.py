@@ -75,7 +75,8 @@ def test_explicit_uniform_operator_equals_default(ext):
     x = scenes.deform(sc, 0.1)
     r_d = TE.emulate(ts_d, x, 5e-5, 2e-4, 2)
     r_x = TE.emulate(ts_x, x, 5e-5, 2e-4, 2)
-    assert r_d[0] == r_x[0] and np.array_equal(r_d[3], r_x[3])
+    # (not bitwise: the built-in path evaluates 4 * own - sum with a missing face reading own, the explicit one deg * own - sum)
+    assert abs(r_d[0] - r_x[0]) <= 1e-13 * abs(r_d[0]) and np.abs(r_d[3] - r_x[3]).max() <= 1e-12 * np.abs(r_d[3]).max()
 
 
 def test_operator_validation(ext):

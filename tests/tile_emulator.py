@@ -99,8 +99,12 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         lv = lv16 // 16
         owned = (pl[0] & OWNED) != 0
         assert np.array_equal(owned, (pl[2] & OWNED) != 0), "owned bit must agree in lv and nbr planes"
-        nb = np.stack([pl[2] & 0x1fff, (pl[2] >> 16) & 0x1fff, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
-        deg_packed = (pl[2] >> 29).astype(np.int64)
+        # neighbour fields are record tokens 12 * idx + rot (plan.h: record_token); a face without a usable
+        # neighbour points at the slot's own record
+        tok = np.stack([pl[2] & 0x7fff, (pl[2] >> 16) & 0x7fff, pl[3] & 0x7fff, (pl[3] >> 16) & 0x7fff], axis=1).astype(np.int64)
+        nb = tok // 12
+        assert np.array_equal(tok % 12, (nb >> 3) & 3), "token = 12 * idx + ((idx >> 3) & 3)"
+        assert np.all((pl[2] >> 31) == 0) and np.all(((pl[3] >> 15) & 1) == 0) and np.all((pl[3] >> 31) == 0)
         dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
         assert owned.sum() == T["n_owned"]
         xs = x[T["gvid"]]
@@ -125,16 +129,17 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         perm = (slots % spt) * nq + slots // spt
         Fz = np.zeros((sp + 1, 9))
         Fz[perm] = F.reshape(sp, 9)
-        assert np.array_equal(deg_packed, (nb != ZS).sum(axis=1)), "packed degree must equal the neighbour count"
-        deg = deg_packed.astype(np.float64)
-        if pl.shape[0] == 13:                 # uniform umbrella, weights implied
-            wd = deg
+        self_idx = perm                        # LDS record of every slot
+        missing = nb == self_idx[:, None]
+        assert nb.max() < sp, "no neighbour field may point at the zero slot any more"
+        if pl.shape[0] == 13:                 # uniform umbrella: 4 * own - sum of the four (a missing face reads own)
+            wd = 4.0 * np.ones(sp)
             wr = wc = -np.ones((sp, 4))
         else:                                 # explicit element operator: L[e,e], L[e,n_k], L[n_k,e]
             wd = pl[13].view(np.float32).astype(np.float64)
             wr = pl[14:18].view(np.float32).astype(np.float64).T
             wc = pl[18:22].view(np.float32).astype(np.float64).T
-            assert np.all(wr[nb == ZS] == 0) and np.all(wc[nb == ZS] == 0)
+            assert np.all(wr[missing] == 0) and np.all(wc[missing] == 0)
         H = wd[:, None] * F.reshape(sp, 9) + (wr[:, :, None] * Fz[nb]).sum(axis=1)
         H[~owned] = 0.0
         Es += 0.5 * float((H * H).sum())

@@ -79,20 +79,30 @@ def main():
         print(f"mask {mask:3d} {what:50s} tile {row['tile_ms']:.4f} ms  finish {row['finish_ms']:.4f} ms  "
               f"{row['gtets_per_s']:.2f} Gtet/s", flush=True)
     _capi.check(lib.tsamd_debug_set_ablation(ts._handle(), 0))
-    # per-phase shader-clock stamps of thread 0 of every tile
+    # per-phase shader-clock stamps of lane 0 of every wave of every tile
     import numpy as np
-    clk = np.zeros(16 * info["n_tiles"], dtype=np.int64)
+    nw = (info["block_threads"] + 63) // 64
+    clk = np.zeros(256 * info["n_tiles"], dtype=np.int64)
     _capi.check(lib.tsamd_debug_read_clocks(ts._handle(), clk.ctypes.data, clk.size))      # arm
     _capi.check(lib.tsamd_forward_backward(ts._handle(), x.data_ptr(), None, 1e-4, 2e-4, 2, stream,
                                            e.data_ptr(), g.data_ptr()))
     _capi.check(lib.tsamd_debug_read_clocks(ts._handle(), clk.ctypes.data, clk.size))      # read
-    clk = clk.reshape(-1, 16)[:, :10]
+    clk = clk.reshape(-1, 16, 16)[:, :nw, :10].astype(np.float64)
     names = ["load+stage", "pass1", "pass2", "H write+reload issue", "pass3 (own wave)", "wait others",
              "force write", "vertex gather+stores", "energy reduce"]
-    d = np.diff(clk, axis=1)
-    out["phase_cycles_mean"] = {n: float(d[:, i].mean()) for i, n in enumerate(names)}
-    print("phase cycles (mean over tiles, thread 0): " +
-          ", ".join(f"{n} {d[:, i].mean():.0f}" for i, n in enumerate(names)) + f", total {(clk[:, 9] - clk[:, 0]).mean():.0f}")
+    d = np.diff(clk, axis=2)                       # [tile, wave, phase]
+    t0 = clk[:, :, 0].min(axis=1, keepdims=True)
+    out["phase_cycles_mean_wave0"] = {n: float(d[:, 0, i].mean()) for i, n in enumerate(names)}
+    print("phase cycles, wave 0 (mean over tiles): " + ", ".join(f"{n} {d[:, 0, i].mean():.0f}" for i, n in enumerate(names)) +
+          f", total {(clk[:, 0, 9] - clk[:, 0, 0]).mean():.0f}")
+    print("per wave: mean cycles spent in each phase (rows = waves)")
+    print("wave " + " ".join(f"{n[:10]:>10s}" for n in names))
+    for w in range(nw):
+        print(f"{w:4d} " + " ".join(f"{d[:, w, i].mean():10.0f}" for i in range(len(names))))
+    out["phase_cycles_by_wave"] = d.mean(axis=0).tolist()
+    # arrival spread at every stamp: last wave minus first wave (what a barrier right after it costs the early ones)
+    spread = clk.max(axis=1) - clk.min(axis=1)
+    print("arrival spread (last wave - first wave) at each stamp: " + ", ".join(f"{spread[:, k].mean():.0f}" for k in range(10)))
     print(json.dumps(out))
 
 

@@ -34,7 +34,7 @@ def tile_conflicts(T, spt):
     nq = sp // spt
     pl = T["planes"]
     owned_slot = (pl[0] & 0x8000) != 0
-    nb = np.stack([pl[2] & 0x1fff, (pl[2] >> 16) & 0x1fff, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64)
+    nb = (np.stack([pl[2] & 0x7fff, (pl[2] >> 16) & 0x7fff, pl[3] & 0x7fff, (pl[3] >> 16) & 0x7fff], axis=1).astype(np.int64)) // 12
     res = dict(g128_base=0, g128_extra=0, g32_base=0, g32_extra=0, v_base=0, v_extra=0)
     for p in range(spt):
         for wbase in range(0, nq, 64):

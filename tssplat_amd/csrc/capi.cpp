@@ -390,8 +390,8 @@ int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capaci
 {
     if (!h || !host_out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
     if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
-    const int64_t need = int64_t(h->plan.tiles.size()) * 16;
-    if (capacity < need) return fail(TSAMD_ERR_INVALID_ARGUMENT, "capacity too small: need 16 entries per tile");
+    const int64_t need = int64_t(h->plan.tiles.size()) * 256;
+    if (capacity < need) return fail(TSAMD_ERR_INVALID_ARGUMENT, "capacity too small: need 256 entries (16 waves x 16 stamps) per tile");
     DeviceGuard g;
     TSAMD_HIP(g.enter(h->device));
     if (!h->d_clk) {   // first call arms the stamps; the next evaluation fills them

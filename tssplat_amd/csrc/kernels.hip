@@ -94,56 +94,76 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
             F[3 * i + j] = Ds[3 * i + 0] * dm[j][p] + Ds[3 * i + 1] * dm[3 + j][p] + Ds[3 * i + 2] * dm[6 + j][p];
 }
 
-// One 48-byte LDS record holds F (later H) as two float quads plus a tail quad, later the 4 x 3 vertex
-// forces.  The ninth matrix entry sits in the tail quad at byte tail_byte(idx): with a fixed position
-// the 48-byte stride would fold every 4-byte neighbour gather onto 8 of the 32 banks; rotating it with
-// bits 3-4 of the record index spreads those gathers over all banks.
+// One 48-byte LDS record (plan.h: record_token) = [tail quad | entries 0..3 | entries 4..7] holds F, later H, later
+// the 4 x 3 vertex forces.  A record is named by the byte address `t` of its ninth matrix entry, which sits in the
+// tail quad at a dword that rotates with bits 3-4 of the record index (at a fixed position the 48-byte stride
+// would fold the 4-byte gathers of it onto 8 of the 32 banks); `t & ~15` is the record base.  The neighbour
+// planes store t / 4, so a gathered record costs one shift and one mask of address arithmetic -- the kernel is
+// bound by instruction issue (profiles/r02_experiments.md), and the round-1 form (index * 48, then the rotation
+// recomputed from the index) spent five VALU instructions per record on it.
 struct Mat9 {
-    v2f p01, p23, p45, p67;  // packed pairs: v_pk_{mul,add,fma}_f32 work on these at twice the scalar rate
+    v2f p01, p23, p45, p67;
     float p8;
 };
 
-__device__ __forceinline__ uint32_t tail_byte(uint32_t idx) { return 32u + ((idx >> 1) & 12u); }
-
-__device__ __forceinline__ Mat9 load_slot(const unsigned char *lds, uint32_t idx)
+// LDS accesses by absolute byte address.  The kernels' only LDS object is the dynamic array, which starts at LDS
+// address 0 (checked at kernel entry); addressing it as `smem + offset` makes the compiler add the array's link-time
+// address -- a literal 0 -- to every computed offset: one wasted VALU instruction per access in a kernel that is
+// bound by instruction issue.
+#define LDS_AS __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ LDS_AS T *lds_at(uint32_t byte_addr)
 {
-    const unsigned char *s = lds + idx * 48u;
-    const v4f a = *reinterpret_cast<const v4f *>(s), b = *reinterpret_cast<const v4f *>(s + 16);
+    return (LDS_AS T *)(uintptr_t)byte_addr;
+}
+
+__device__ __forceinline__ uint32_t own_token_addr(uint32_t idx) { return 48u * idx + ((idx >> 1) & 12u); }
+
+__device__ __forceinline__ Mat9 load_slot(const unsigned char *, uint32_t t)
+{
+    const uint32_t s = t & ~15u;
+    const v4f a = *lds_at<const v4f>(s + 16), b = *lds_at<const v4f>(s + 32);
     Mat9 m;
     m.p01 = a.xy; m.p23 = a.zw; m.p45 = b.xy; m.p67 = b.zw;
-    m.p8 = *reinterpret_cast<const float *>(s + tail_byte(idx));
+    m.p8 = *lds_at<const float>(t);
     return m;
 }
 
-// Own-slot accesses: consecutive lanes walk consecutive records; 16-byte accesses of the two quads are
-// conflict-free, and so are the 4-byte ones of the rotated tail entry (32 consecutive records -> 32 banks).
-__device__ __forceinline__ Mat9 load_own_slot(const unsigned char *lds, uint32_t idx) { return load_slot(lds, idx); }
-
 // Stores cost 2 cycles per source dword on the VGPR -> LDS path, so the tail goes out as one dword, not a quad.
-__device__ __forceinline__ void store_slot(unsigned char *lds, uint32_t idx, const float *m)
+__device__ __forceinline__ void store_slot(unsigned char *, uint32_t t, const float *m)
 {
-    unsigned char *s = lds + idx * 48u;
-    *reinterpret_cast<v4f *>(s) = v4f{m[0], m[1], m[2], m[3]};
-    *reinterpret_cast<v4f *>(s + 16) = v4f{m[4], m[5], m[6], m[7]};
-    *reinterpret_cast<float *>(s + tail_byte(idx)) = m[8];
+    const uint32_t s = t & ~15u;
+    *lds_at<v4f>(s + 16) = v4f{m[0], m[1], m[2], m[3]};
+    *lds_at<v4f>(s + 32) = v4f{m[4], m[5], m[6], m[7]};
+    *lds_at<float>(t) = m[8];
 }
 
-// acc = deg * own - sum of the four neighbours (zero slot for a missing one)
-__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, const Mat9 &own, float deg, const uint32_t *nb)
+// acc = 4 * own - sum of the four neighbour records.  A face without a neighbour points at the slot's own record
+// (plan.h), so it contributes own - own = 0: no degree, no dummy record, no branch.
+__device__ __forceinline__ void sub9(Mat9 &acc, const Mat9 &g)
 {
-    Mat9 acc;
-    acc.p01 = own.p01 * deg; acc.p23 = own.p23 * deg; acc.p45 = own.p45 * deg; acc.p67 = own.p67 * deg;
-    acc.p8 = own.p8 * deg;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const Mat9 g = load_slot(lds, nb[k]);
-        acc.p01 -= g.p01; acc.p23 -= g.p23; acc.p45 -= g.p45; acc.p67 -= g.p67;
-        acc.p8 -= g.p8;
-    }
+    acc.p01 -= g.p01; acc.p23 -= g.p23; acc.p45 -= g.p45; acc.p67 -= g.p67;
+    acc.p8 -= g.p8;
+}
+
+__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, uint32_t t_own, const uint32_t *nb)
+{
+    Mat9 acc = load_slot(lds, t_own);
+    Mat9 g0 = load_slot(lds, nb[0]);
+    acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
+    acc.p8 *= 4.f;
+    Mat9 g1 = load_slot(lds, nb[1]);
+    sub9(acc, g0);
+    g0 = load_slot(lds, nb[2]);
+    sub9(acc, g1);
+    g1 = load_slot(lds, nb[3]);
+    sub9(acc, g0);
+    sub9(acc, g1);
     return acc;
 }
 
-// explicit element operator: acc = dg * own + sum_k w[k] * neighbour_k  (the weights carry their sign)
+// explicit element operator: acc = dg * own + sum_k w[k] * neighbour_k  (the weights carry their sign; 0 for a
+// face that points at the slot itself)
 __device__ __forceinline__ Mat9 operator_gather(const unsigned char *lds, const Mat9 &own, float dg, const float *w,
                                                 const uint32_t *nb)
 {
@@ -175,7 +195,7 @@ struct KernelArgs {
     int n_tiles;
     int tiles_per_xcd;
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
-    long long *clk;  // ablation builds: 16 shader-clock stamps per tile (phase boundaries of thread 0)
+    long long *clk;  // ablation builds: 16 shader-clock stamps per wave (up to 16 waves) per tile
 };
 
 enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
@@ -185,7 +205,7 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 #define DBG(flag) ((a.dbg & (flag)) != 0)
 #define STAMP(k)                                                          \
     do {                                                                  \
-        if (a.clk && threadIdx.x == 0) a.clk[16 * size_t(tile) + (k)] = clock64(); \
+        if (a.clk && (threadIdx.x & 63) == 0) a.clk[(16 * size_t(tile) + (threadIdx.x >> 6)) * 16 + (k)] = clock64(); \
     } while (0)
 #else
 #define DBG(flag) false
@@ -258,7 +278,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
     }
-    if (tid < 12) reinterpret_cast<float *>(smem + ZS * 48u)[tid] = 0.f;  // the all-zero slot (first read in pass 2)
+
     // stage this tile's vertex positions; the fence keeps the compiler from waiting for the vertex id (and so for
     // nothing else: vmcnt(13)) before the plane loads above have been issued
     __builtin_amdgcn_sched_barrier(0);
@@ -280,8 +300,18 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         return;
     }
 
+    // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
+    // dE/dF = c1 (Q + (c2 / c1) pen' cof F), so pass 3 works with s_pen = c2 / c1 and the per-vertex sums are scaled
+    // by c1 (and by grad_output) when they are written.  c1 == 0 drops Q instead.
+    const bool use_c1 = k_c1 != 0.f;
+    const float s_pen = use_c1 ? k_c2 / k_c1 : k_c2, out_scale = use_c1 ? k_c1 : 1.f;
+    // byte address of each own record's ninth entry (see load_slot), once per slot instead of once per access
+    uint32_t t_own[SPT];
+#pragma unroll
+    for (int p = 0; p < SPT; ++p) t_own[p] = own_token_addr(uint32_t(p * nq + tid));
+
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
-    float scal[SPT];  // c2 * d(penalty)/d(det F), 0 unless owned and inverted
+    float scal[SPT];  // (c2 / c1) * d(penalty)/d(det F), 0 unless owned and inverted
 #pragma unroll
     for (int p = 0; p < SPT; ++p) scal[p] = 0.f;
     float e_b = 0.f, e_s = 0.f;
@@ -303,9 +333,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             }
             if (w0 & kOwnedBit) {
                 e_b += pen;
-                scal[p] = k_c2 * dpen;
+                scal[p] = s_pen * dpen;
             }
-            store_slot(smem, uint32_t(p * nq + tid), F);
+            store_slot(smem, t_own[p], F);
             SLOT_FENCE();
         }
     }
@@ -321,22 +351,26 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // are the owned ones, so `owned` is uniform across all but one wave per position: halo slots
     // skip their gathers with a real branch.
     float H[SPT][9];
+    auto neighbours = [](uint32_t n01, uint32_t n23, uint32_t *nb) {   // byte addresses of the four records' ninth entries
+        nb[0] = (n01 & kNbMask) << 2;
+        nb[1] = (n01 >> 14) & (kNbMask << 2);
+        nb[2] = (n23 & kNbMask) << 2;
+        nb[3] = (n23 >> 14) & (kNbMask << 2);
+    };
     if (active && !DBG(DBG_SKIP_P2)) {
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
             const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
-#pragma unroll
-            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
             if (n01 & kOwnedBit) {
-                uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
-                const uint32_t so = uint32_t(p * nq + tid);
-                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = so;
+                uint32_t nb[4];
+                neighbours(n01, n23, nb);
+                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = t_own[p];
                 Mat9 h;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    h = operator_gather(smem, load_own_slot(smem, so), wd[p], w4, nb);
+                    h = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
-                    h = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                    h = laplace_gather(smem, t_own[p], nb);
                 }
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
@@ -346,17 +380,26 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 H[p][0] = h.p01.x; H[p][1] = h.p01.y; H[p][2] = h.p23.x; H[p][3] = h.p23.y;
                 H[p][4] = h.p45.x; H[p][5] = h.p45.y; H[p][6] = h.p67.x; H[p][7] = h.p67.y;
                 H[p][8] = h.p8;
+            } else {   // halo / padding slot: H = 0.  (Defined on this path only: owned lanes do not pay for it, and an
+                       // array left undefined on a path is given registers from the kernel entry on.)
+#pragma unroll
+                for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
             }
             SLOT_FENCE();  // keep one slot's gathers in flight, not four (VGPR budget)
         }
+    } else {
+#pragma unroll
+        for (int p = 0; p < SPT; ++p)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
     }
     __syncthreads();  // every read of F is done; overwrite it with H in place
     STAMP(3);  // pass 2 done
 
     if (WITH_GRAD) {
-        // vertex incidence lists: lanes 2v and 2v+1 gather local vertex v, one taking the even chunks of its
-        // list and one the odd ones.  Each fetches its first kPre chunks now so that their HBM latency hides
-        // behind pass 3.
+        // vertex incidence lists.  The first K2 vertices of the tile get two lanes each (2v and 2v+1 take the even
+        // and the odd chunks), the others one lane (plan.h: vertex_two_lane_count): every vertex is served in one
+        // round.  Each lane fetches its first kPre chunks now so that their HBM latency hides behind pass 3.
         constexpr int kPre = 3;
         const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + (WEIGHTED ? kPlanesWeighted : kPlanes) * td.s_pad);
         const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
@@ -374,7 +417,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
             }
 #pragma unroll
-            for (int p = 0; p < SPT; ++p) store_slot(smem, uint32_t(p * nq + tid), H[p]);
+            for (int p = 0; p < SPT; ++p) store_slot(smem, t_own[p], H[p]);   // (zeros on halo and padding slots)
             if (WEIGHTED) {   // pass 3 applies L^T: the column weights L[n_k, e]
 #pragma unroll
                 for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
@@ -383,32 +426,41 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         __syncthreads();
         STAMP(4);  // H written, reloads issued
 
-        // ---- pass 3: P = c1 L^T H + c2 dpen cof(F);  d = P Dm^-T (per-tet vertex forces) ----
+        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
         // Held in registers across the barrier, then written over H (all reads of it done by then).
         float D[SPT][9];
         if (active && !DBG(DBG_SKIP_P3)) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
-                const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
-                uint32_t nb[4] = {n01 & kSlotMask, (n01 >> 16) & kSlotMask, n23 & 0xffffu, n23 >> 16};
-                const uint32_t so = uint32_t(p * nq + tid);
-                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = so;
+                uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
+                // (opaque copies: otherwise the eight record addresses decoded in pass 2 are kept in registers across
+                // two barriers for reuse here -- 16 VGPRs that push the kernel over its 80-register budget)
+                asm volatile("" : "+v"(n01), "+v"(n23));
+                uint32_t nb[4];
+                neighbours(n01, n23, nb);
+                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = t_own[p];
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
                 Mat9 q;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    q = operator_gather(smem, load_own_slot(smem, so), wd[p], w4, nb);
+                    q = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
-                    q = laplace_gather(smem, load_own_slot(smem, so), float(n01 >> kDegShift), nb);
+                    q = laplace_gather(smem, t_own[p], nb);
                 }
-                q.p01 *= k_c1; q.p23 *= k_c1; q.p45 *= k_c1; q.p67 *= k_c1;
-                q.p8 *= k_c1;
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
+                if (!use_c1) {   // smoothness switched off: only the penalty term is left
+#pragma unroll
+                    for (int c = 0; c < 9; ++c) P[c] = 0.f;
+                }
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    if (!kReload) {  // rare path: fetch the vertex offsets again instead of pinning them
-                        q_lv01 = plane_u(0);
-                        q_lv23 = plane_u(1);
+                    if (!kReload) {  // rare path: fetch the vertex offsets again instead of pinning them (the address is
+                                     // rebuilt from an opaque copy of the lane id, or it would be kept in two VGPRs
+                                     // from the stream phase on)
+                        int lt2 = lt;
+                        asm volatile("" : "+v"(lt2));
+                        q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
+                        q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt2);
                     }
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
@@ -431,15 +483,19 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
+        // (computed here, not earlier: nothing of it needs to stay live across pass 3)
+        const int K2 = td.n_verts <= nthr ? (td.n_verts < nthr - td.n_verts ? td.n_verts : nthr - td.n_verts) : 0;  // = plan.h: vertex_two_lane_count
+        const bool two_lane = tid < 2 * K2;
+        const int my_v = two_lane ? tid >> 1 : K2 + (tid - 2 * K2), my_stride = two_lane ? 2 : 1;
+        const bool has_vertex = my_v < td.n_verts;
         int32_t dst_row = 0;  // where this lane's vertex goes: fetched here, a whole phase ahead of its use
-        if (tid < 2 * td.n_verts) {
-            const int v = tid >> 1;
-            pc0 = inc_off[v] + (tid & 1);
-            pc1 = inc_off[v + 1];
-            dst_row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
+        if (has_vertex) {
+            pc0 = inc_off[my_v] + (two_lane ? (tid & 1) : 0);
+            pc1 = inc_off[my_v + 1];
+            dst_row = my_v < td.n_excl ? g_gvid[td.vert_off + my_v] : g_sdst[td.stage_off + (my_v - td.n_excl)];
 #pragma unroll
             for (int q = 0; q < kPre; ++q)
-                pre[q] = pc0 + 2 * q < pc1 ? inc[pc0 + 2 * q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
+                pre[q] = pc0 + my_stride * q < pc1 ? inc[pc0 + my_stride * q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
         }
         STAMP(5);  // pass 3 compute done (this wave)
         __syncthreads();
@@ -448,31 +504,31 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         if (active) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
-                unsigned char *r = smem + uint32_t(p * nq + tid) * 48u;
+                const uint32_t r = t_own[p] & ~15u;
                 const float *d = D[p];
-                *reinterpret_cast<v4f *>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
-                *reinterpret_cast<v4f *>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
-                *reinterpret_cast<v4f *>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
+                *lds_at<v4f>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
+                *lds_at<v4f>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
+                *lds_at<v4f>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
             }
         }
+        if (tid < 12) lds_at<float>(ZS * 48u)[tid] = 0.f;  // the all-zero record the list padding points at
         __syncthreads();
         STAMP(7);  // vertex forces written
 
         // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
-        // Entry e = (lds slot << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
+        // Entry e = (lds record << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
         // point into the all-zero slot.  Exclusive vertices go straight to grad, vertices shared with
         // other tiles to the staging rows, which the finish kernel sums in plan order.
         // The plan sorts a tile's vertices by list length, so the lanes of one wave need about the same
         // number of chunks and a wave stops at its own longest list.
-        const float gscale = a.grad_out ? *as_global(a.grad_out) : 1.f;
-        for (int u = tid; u < 2 * td.n_verts; u += nthr) {
-            const int v = u >> 1;
+        const float gscale = (a.grad_out ? *as_global(a.grad_out) : 1.f) * out_scale;
+        for (int v = my_v, round = 0; v < td.n_verts; v += nthr, ++round) {   // (a second round only if n_verts > nthr)
             float gx = 0.f, gy = 0.f, gz = 0.f;
             auto gather4 = [&](const v2u w) {
                 const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float *f = reinterpret_cast<const float *>(smem + ent[q] * 12u);
+                    const LDS_AS float *f = lds_at<const float>(ent[q] * 12u);
                     gx += f[0];
                     gy += f[1];
                     gz += f[2];
@@ -481,29 +537,31 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             int32_t row = dst_row;
             if (!DBG(DBG_SKIP_VGATHER)) {
                 int c, c1;
-                if (u == tid) {  // prefetched chunks; a wave skips the steps none of its lanes needs
+                if (round == 0) {  // prefetched chunks; a wave skips the steps none of its lanes needs
                     c = pc0;
                     c1 = pc1;
 #pragma unroll
                     for (int q = 0; q < kPre; ++q) {
                         if (__builtin_amdgcn_ballot_w64(c < c1) == 0) break;
                         gather4(pre[q]);
-                        c += 2;
+                        c += my_stride;
                     }
                 } else {
-                    c = inc_off[v] + (u & 1);
+                    c = inc_off[v];
                     c1 = inc_off[v + 1];
                     row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
                 }
-                for (; c < c1; c += 2) gather4(inc[c]);
+                for (; c < c1; c += my_stride) gather4(inc[c]);
             }
-            // even lane + odd lane (quad_perm [1,0,3,2]); both lanes end up with the same sum
-            gx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gx), 0xB1, 0xf, 0xf, false));
-            gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xf, 0xf, false));
-            gz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0xB1, 0xf, 0xf, false));
-            if (u & 1) continue;
+            if (two_lane) {
+                // even lane + odd lane (quad_perm [1,0,3,2]); both lanes end up with the same sum
+                gx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gx), 0xB1, 0xf, 0xf, false));
+                gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xf, 0xf, false));
+                gz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0xB1, 0xf, 0xf, false));
+                if (tid & 1) continue;
+            }
             GLOBAL_AS float *dst = (v < td.n_excl ? g_grad : g_stage) + size_t(row) * 3;
-            const float sc = v < td.n_excl ? gscale : 1.f;
+            const float sc = v < td.n_excl ? gscale : out_scale;
             if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
                 continue;
@@ -552,6 +610,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
     const int tile = xcd * a.tiles_per_xcd + jb;
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
+    // (lds_at() assumes the dynamic LDS array starts at LDS address 0: true for a kernel without static LDS objects.  A
+    // run-time check here costs more than it looks: a trap in the prologue turns the descriptor loads into vector loads
+    // and their 12 dwords, and every address derived from them, into VGPRs -- measured +26 VGPRs.)
     const TileDesc td0 = a.tiles[tile];
     tile_body<WITH_GRAD, SPT, WEIGHTED>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
 }

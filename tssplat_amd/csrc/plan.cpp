@@ -322,7 +322,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 80 * 1024;
     const int spt = opt.slots_per_thread == 4 ? 4 : 2;
-    lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 8188);  // slot ids are 13-bit fields
+    lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 2728);  // record tokens (12 idx + rot) are 15-bit fields
     if (lim.budget < tile_lds_bytes(8, 8)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
@@ -675,10 +675,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             }
             uint32_t *pl = P.blob.data() + d.blob_off / 4;
             const uint32_t ZS = uint32_t(d.s_pad);
-            // padding defaults: lv = 0, nbr = zero slot, dminv = 0
+            // padding slots: lv = 0, neighbours = the slot itself, dminv = 0 (F = 0, forces = 0, no incidence entries)
             for (int32_t s = 0; s < d.s_pad; ++s) {
-                pl[2 * size_t(d.s_pad) + s] = ZS | (ZS << 16);
-                pl[3 * size_t(d.s_pad) + s] = ZS | (ZS << 16);
+                const uint32_t f = record_token(uint32_t(lds_index(s, nq, spt)));
+                pl[2 * size_t(d.s_pad) + s] = f | (f << 16);
+                pl[3 * size_t(d.s_pad) + s] = f | (f << 16);
             }
             int32_t *stet = P.slot_tet.data() + P.slot_base[size_t(t)];
             for (int32_t L = 0; L < d.n_slots; ++L) {
@@ -690,10 +691,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 // local vertices as byte offsets into the staged float4 positions (16 B each)
                 for (int a = 0; a < 4; ++a) lv[a] = uint32_t(S.vert_local[tets[4 * int64_t(el) + a]]) << 4;
                 if (owned) lv[0] |= kOwnedBit;
-                uint32_t deg = 0;
+                // neighbour k as an LDS record index; a face without a usable neighbour points at the slot itself
+                const uint32_t self = uint32_t(lds_index(s, nq, spt));
                 for (int k = 0; k < 4; ++k) {
                     int32_t q = P.nbr[4 * size_t(el) + k];
-                    uint32_t v = ZS;
+                    uint32_t v = self;
                     if (q >= 0) {
                         int32_t qs = S.tet_stamp[q];
                         if (owned) {
@@ -703,7 +705,6 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         }
                     }
                     nb[k] = v;
-                    deg += v != ZS;
                 }
                 if (weighted) {   // planes 13..21: L[e,e], L[e,n_k], L[n_k,e] in the (not yet re-ordered) neighbour order
                     auto putf = [&](int plane, float v) { std::memcpy(&pl[size_t(plane) * size_t(d.s_pad) + s], &v, 4); };
@@ -711,7 +712,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     for (int k = 0; k < 4; ++k) {
                         const int32_t q = P.nbr[4 * size_t(el) + k];
                         float wr = 0.f, wc = 0.f;
-                        if (q >= 0 && nb[k] != ZS) {
+                        if (q >= 0 && nb[k] != self) {
                             wr = P.op_w[4 * size_t(el) + k];
                             for (int f = 0; f < 4; ++f)
                                 if (P.nbr[4 * size_t(q) + f] == el) wc = P.op_w[4 * size_t(q) + f];
@@ -722,8 +723,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 }
                 pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
                 pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
-                pl[2 * size_t(d.s_pad) + s] = nb[0] | (owned ? kOwnedBit : 0u) | (nb[1] << 16) | (deg << kDegShift);
-                pl[3 * size_t(d.s_pad) + s] = nb[2] | (nb[3] << 16);
+                pl[2 * size_t(d.s_pad) + s] = record_token(nb[0]) | (owned ? kOwnedBit : 0u) | (record_token(nb[1]) << 16);
+                pl[3 * size_t(d.s_pad) + s] = record_token(nb[2]) | (record_token(nb[3]) << 16);
                 // Dm^-1 in double from the fp32 rest positions, rounded to fp32
                 const int32_t *tt = tets + 4 * int64_t(el);
                 double D[9];
@@ -773,21 +774,21 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 if (tl >= nq) continue;
                                 const int32_t sl = spt * tl + pp;
                                 lane_slot[nl] = sl;
-                                cand[nl][0] = p2[sl] & kSlotMask;
-                                cand[nl][1] = (p2[sl] >> 16) & kSlotMask;
-                                cand[nl][2] = p3[sl] & 0xffffu;
-                                cand[nl][3] = p3[sl] >> 16;
+                                cand[nl][0] = token_record(p2[sl] & kNbMask);
+                                cand[nl][1] = token_record((p2[sl] >> 16) & kNbMask);
+                                cand[nl][2] = token_record(p3[sl] & kNbMask);
+                                cand[nl][3] = token_record((p3[sl] >> 16) & kNbMask);
                                 ++nl;
                             }
                             uint32_t chosen[16][4];
                             int from[16][4];   // chosen[li][step] is candidate from[li][step] (the weights follow)
-                            colour_group_reads(nl, cand, ZS, from);
+                            colour_group_reads(nl, cand, 0xffffffffu, from);   // (no free reads: a missing face reads the slot itself)
                             for (int li = 0; li < nl; ++li)
                                 for (int step = 0; step < 4; ++step) chosen[li][step] = cand[li][from[li][step]];
                             for (int li = 0; li < nl; ++li) {
                                 const int32_t sl = lane_slot[li];
-                                p2[sl] = (p2[sl] & ~(kSlotMask | (kSlotMask << 16))) | chosen[li][0] | (chosen[li][1] << 16);
-                                p3[sl] = chosen[li][2] | (chosen[li][3] << 16);
+                                p2[sl] = (p2[sl] & kOwnedBit) | record_token(chosen[li][0]) | (record_token(chosen[li][1]) << 16);
+                                p3[sl] = record_token(chosen[li][2]) | (record_token(chosen[li][3]) << 16);
                                 if (weighted)
                                     for (int base_plane : {14, 18}) {
                                         uint32_t old[4];
@@ -825,37 +826,52 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq, spt)) << 2) | uint32_t(a));
                     }
                 }
-                // Conflict-aware order inside every list.  Lanes 2v and 2v+1 walk the even and the odd chunks of
-                // vertex v, so one ds_read_b32 (32-lane groups, bank = (3 * entry + c) mod 32 for the float at
-                // byte 12 * entry + 4 c) serves 16 consecutive vertices and reads, at step (j, q), list positions
-                // 8 j + q and 8 j + 4 + q of each.  Two lanes collide when their entries agree mod 32.  List
-                // order is free (it only fixes the summation order): per group and step, hand every lane a
-                // not yet placed entry of its vertex with an unused residue.
+                // Conflict-aware order inside every list.  The kernel gives the first K2 vertices two lanes each
+                // (lanes 2v, 2v+1 take the even / odd 4-entry chunks) and the others one lane (vertex_gather_lanes).
+                // One ds_read_b32 serves a 32-lane group (bank = (3 * entry + c) mod 32 for the float at byte
+                // 12 * entry + 4 c): at step (j, q) lane (v, h, stride) reads list position 4 (h + stride j) + q of its
+                // vertex, and two lanes collide when their entries agree mod 32.  List order is free (it only fixes
+                // the summation order): per group and step, hand every lane a not yet placed entry of its vertex with
+                // an unused residue.
                 if (opt.conflict_aware) {
-                    std::vector<uint8_t> placed;
-                    for (int32_t vb = 0; vb < d.n_verts; vb += 16) {
-                        const int32_t ve = std::min<int32_t>(vb + 16, d.n_verts);
-                        int32_t maxlen = 0;
-                        for (int32_t v = vb; v < ve; ++v) maxlen = std::max(maxlen, cnt[size_t(v)]);
-                        placed.assign(size_t(16) * size_t(maxlen + 8), 0);
-                        for (int32_t j = 0; 8 * j < maxlen; ++j)
+                    const int32_t K2 = vertex_two_lane_count(d.n_verts, P.block_threads);
+                    const int32_t n_lanes = std::min<int32_t>(2 * K2 + (d.n_verts - K2), std::max(P.block_threads, 2 * K2));
+                    std::vector<uint8_t> placed(4 * size_t(d.n_inc4) + 8, 0);
+                    for (int32_t l0 = 0; l0 < n_lanes; l0 += 32) {
+                        const int32_t l1 = std::min<int32_t>(l0 + 32, n_lanes);
+                        int32_t steps = 0;
+                        auto lane_of = [&](int32_t L, int32_t &v, int32_t &h, int32_t &stride) {
+                            if (L < 2 * K2) {
+                                v = L >> 1, h = L & 1, stride = 2;
+                            } else {
+                                v = K2 + (L - 2 * K2), h = 0, stride = 1;
+                            }
+                        };
+                        for (int32_t L = l0; L < l1; ++L) {
+                            int32_t v, h, stride;
+                            lane_of(L, v, h, stride);
+                            const int32_t chunks = (cnt[size_t(v)] + 3) / 4;
+                            steps = std::max(steps, (chunks - h + stride - 1) / stride);
+                        }
+                        for (int32_t j = 0; j < steps; ++j)
                             for (int32_t q = 0; q < 4; ++q) {
                                 int32_t colrec[32];
                                 for (auto &c : colrec) c = -1;
-                                for (int32_t v = vb; v < ve; ++v)
-                                    for (int32_t h = 0; h < 2; ++h) {
-                                        const int32_t pos = 8 * j + 4 * h + q, len = cnt[size_t(v)];
-                                        if (pos >= len) continue;
-                                        uint16_t *lst = inc + 4 * size_t(inc_off[v]);
-                                        uint8_t *pl_v = placed.data() + size_t(v - vb) * size_t(maxlen + 8);
-                                        int32_t pick = -1;
-                                        for (int32_t c = 0; c < len && pick < 0; ++c)
-                                            if (!pl_v[c] && colrec[lst[c] & 31u] < 0) pick = c;
-                                        if (pick < 0) pick = pos;  // pos itself is never placed before its own step
-                                        std::swap(lst[pos], lst[pick]);
-                                        pl_v[pos] = 1;
-                                        if (colrec[lst[pos] & 31u] < 0) colrec[lst[pos] & 31u] = lst[pos];
-                                    }
+                                for (int32_t L = l0; L < l1; ++L) {
+                                    int32_t v, h, stride;
+                                    lane_of(L, v, h, stride);
+                                    const int32_t pos = 4 * (h + stride * j) + q, len = cnt[size_t(v)];
+                                    if (pos >= len) continue;
+                                    uint16_t *lst = inc + 4 * size_t(inc_off[v]);
+                                    uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[v]);
+                                    int32_t pick = -1;
+                                    for (int32_t c = 0; c < len && pick < 0; ++c)
+                                        if (!pl_v[c] && colrec[lst[c] & 31u] < 0) pick = c;
+                                    if (pick < 0) pick = pos;  // pos itself is never placed before its own step
+                                    std::swap(lst[pos], lst[pick]);
+                                    pl_v[pos] = 1;
+                                    if (colrec[lst[pos] & 31u] < 0) colrec[lst[pos] & 31u] = lst[pos];
+                                }
                             }
                     }
                 }

@@ -45,7 +45,7 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI
 
 // Per tile, in this order, inside the blob:
 //   13 planes of s_pad dwords : lv01, lv23, nb01, nb23, dminv[9]        (tet-slot major, 52 B / slot)
-//   n_inc4 chunks of 4 x u16  : vertex incidence entries (slot << 2 | local vertex a), grouped by
+//   n_inc4 chunks of 4 x u16  : vertex incidence entries (LDS record index << 2 | local vertex a), grouped by
 //                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
 //   n_verts + 1 x u16         : first chunk of every local vertex
 constexpr int kPlanes = 13;
@@ -59,12 +59,30 @@ constexpr int kPlanesWeighted = 22;
 // Index planes, two 16-bit fields per dword:
 //   lv01 = (16 * v0 | owned << 15) | (16 * v1) << 16      vertex ids pre-multiplied to byte offsets
 //   lv23 = (16 * v2)               | (16 * v3) << 16      into the staged float4 positions
-//   nb01 = (n0 | owned << 15)      | (n1 | deg << 13) << 16   n = LDS slot index of the face neighbour
-//   nb23 =  n2                     |  n3 << 16                (s_pad = the all-zero slot), deg = #neighbours
+//   nb01 = (f0 | owned << 15)      | f1 << 16             f = record_token(LDS record index of the face neighbour):
+//   nb23 =  f2                     | f3 << 16             a quarter of the byte address of the record's ninth entry
+// A face without a neighbour in the tile (mesh boundary; for halo slots: any neighbour that is not owned by the
+// tile) points at the slot's OWN record: the kernels evaluate 4 * own - sum of the four, so such a face adds
+// own - own = 0 and neither a degree nor a dummy record is needed.
 constexpr uint32_t kOwnedBit = 0x8000u;
-constexpr int kDegShift = 29;
-constexpr uint32_t kSlotMask = 0x1fffu;
+constexpr uint32_t kNbMask = 0x7fffu;
+// LDS record of index idx: 48 bytes at 48 * idx = [tail quad | entries 0..3 | entries 4..7]; the ninth matrix entry
+// sits in the tail quad at dword (idx >> 3) & 3 -- rotating it with bits 3-4 of the index spreads the 4-byte
+// gathers of it over all 32 banks (at a fixed position the 48-byte stride folds them onto 8).  The token
+// 12 * idx + rot is what the planes store: token << 2 is the byte address of the ninth entry, and that address
+// with its low four bits cleared is the record base -- one shift and one mask per gathered record.
+inline uint32_t record_token(uint32_t idx) { return 12u * idx + ((idx >> 3) & 3u); }
+inline uint32_t token_record(uint32_t token) { return token / 12u; }
 constexpr int kMaxTileVerts = 2047;
+// Lanes of the per-vertex force gather: with n_verts vertices and nthr lanes, the first K2 vertices of the tile
+// (the ones with the longest incidence lists come first) get two lanes each -- lanes 2v, 2v+1 take the even / odd
+// chunks of the list -- and the other n_verts - K2 one lane each, so that every vertex is served in ONE round and
+// no lane walks a second vertex (round 1: two lanes for everybody, the first 2 n_verts - nthr lanes then took a
+// second vertex, cold, while eleven of the twelve waves waited for them).
+inline int32_t vertex_two_lane_count(int32_t n_verts, int32_t nthr)
+{
+    return n_verts <= nthr ? (n_verts < nthr - n_verts ? n_verts : nthr - n_verts) : 0;
+}
 
 // Where slot s (HBM plane order: thread t streams slots spt*t .. spt*t+spt-1 as one load per plane) lives in
 // the LDS planes.  Lane t keeps its p-th slot at p * nq + t, so the 64 lanes of a wave touch 64
