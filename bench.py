@@ -70,6 +70,7 @@ def parse(argv=None):
     p.add_argument("--lds-budget", type=int, default=0)
     p.add_argument("--target-owned", type=int, default=0)
     p.add_argument("--spt", type=int, default=0, help="slots per thread (2 or 4; 0 = library default)")
+    p.add_argument("--rebuild-dminv", type=int, default=-1, help="1 = rebuild Dm^-1 in registers from rest positions, 0 = stream it, -1 = library default")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-spheres", type=int, default=8)
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (bring-up on a 1-GPU box)")
@@ -259,7 +260,8 @@ def _run_rank(args, stdout_fd: int) -> None:
     t0 = time.time()
     energy = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, max_threads=args.max_threads,
                                      lds_budget_bytes=args.lds_budget, target_owned=args.target_owned,
-                                     slots_per_thread=args.spt)
+                                     slots_per_thread=args.spt,
+                                     rebuild_dminv=None if args.rebuild_dminv < 0 else bool(args.rebuild_dminv))
     t_plan = time.time() - t0
     info = energy.tet_sp.plan_info()
     if rank == 0:

@@ -66,6 +66,10 @@ typedef struct tsamd_options {
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
     int32_t debug_shuffle;     /* experiments: bit0 = spread a tile's tets over lanes, bit1 = no LDS-conflict-aware ordering */
     int32_t slots_per_thread;  /* tets streamed per lane: 2 (8 B loads, default) or 4 (16 B loads)  */
+    int32_t rebuild_dminv;     /* 1 = keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
+                                * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per
+                                * evaluation, entries of Dm^-1 within 2.8e-7 relative of the exact inverse instead of
+                                * 5.9e-8 (double -> fp32 rounding, tet_spheres.cpp:43-45).  Not with an explicit operator. */
 } tsamd_options;
 
 /* Introspection of the tiling plan (host side; valid for host_only handles too). */
@@ -80,7 +84,7 @@ typedef struct tsamd_plan_info {
     int64_t device_bytes;        /* bytes of plan data resident in HBM                              */
     int32_t max_slots, max_tile_vertices, block_threads, lds_bytes;
     int32_t slots_per_thread;
-    int32_t n_planes;            /* dword planes per tile slot: 13, or 22 with an explicit element operator */
+    int32_t n_planes;            /* dword planes per tile slot: 13; 22 with an explicit element operator; 4 with rebuild_dminv */
 } tsamd_plan_info;
 
 /* One tile of the plan, as host pointers into the handle (valid until tsamd_destroy).
@@ -95,6 +99,7 @@ typedef struct tsamd_tile_view {
     const uint16_t *inc_off;  /* n_verts + 1 chunk offsets                                          */
     const int32_t *gvid;      /* n_verts global vertex ids, exclusive ones first                    */
     const int32_t *slot_tet;  /* s_pad global tet ids (-1 = padding)                                */
+    const float *rest;        /* rebuild_dminv plans: n_verts x float4 rest positions (tile vertex order), else NULL */
 } tsamd_tile_view;
 
 const char *tsamd_last_error(void);

@@ -106,6 +106,7 @@ def test_config2_64_spheres(ext, sigma, order):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(balance_slots=False), dict(lds_budget_bytes=40960, max_threads=512),
+                                dict(rebuild_dminv=True), dict(rebuild_dminv=True, max_threads=1024, lds_budget_bytes=163840),
                                 dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840),
                                 dict(slots_per_thread=4, max_threads=512, lds_budget_bytes=81920),
                                 dict(slots_per_thread=2, max_threads=1024, lds_budget_bytes=163840)])

@@ -20,7 +20,8 @@ def ext():
 
 def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
     ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, **kw)
-    cache = O.prepare(sc.rest, sc.tets)
+    # rebuild_dminv plans carry rest positions, not the fp32-rounded Dm^-1: their exact replay is the unrounded operator
+    cache = O.prepare(sc.rest, sc.tets, round_fp32=not kw.get("rebuild_dminv", False))
     assert np.array_equal(TE.adjacency(ts), cache.nbr)
     for sigma, order, go in cases:
         x = scenes.deform(sc, sigma)
@@ -45,6 +46,10 @@ def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
     ("cone", 1, dict(lds_budget_bytes=30000)),
     ("delaunay700", 2, {}),                            # unstructured: irregular valence, holes, no index locality
     ("delaunay2500", 1, dict(lds_budget_bytes=50000, max_threads=512)),
+    ("kuhn12", 1, dict(rebuild_dminv=True)),           # rest positions instead of Dm^-1 planes
+    ("kuhn3", 40, dict(rebuild_dminv=True)),
+    ("cone", 2, dict(rebuild_dminv=True)),
+    ("delaunay700", 2, dict(rebuild_dminv=True, lds_budget_bytes=50000, max_threads=512)),
 ])
 def test_plan_replays_to_oracle(ext, kind, S, kw):
     sc = scenes.make_scene(kind, S)
@@ -58,6 +63,7 @@ def test_plan_replays_to_oracle(ext, kind, S, kw):
     assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 81920)
     assert info["slots_per_thread"] == kw.get("slots_per_thread", 2)
     assert info["slots_per_thread"] * info["block_threads"] >= info["max_slots"]
+    assert info["n_planes"] == (4 if kw.get("rebuild_dminv") else 13)
 
 
 def test_real_mesh_plan(ext, aveg):

@@ -31,8 +31,9 @@ def plan_tiles(ts):
         inc_off = np.ctypeslib.as_array(tv.inc_off, shape=(tv.n_verts + 1,)).copy()
         gvid = np.ctypeslib.as_array(tv.gvid, shape=(tv.n_verts,)).copy()
         slot_tet = np.ctypeslib.as_array(tv.slot_tet, shape=(sp,)).copy()
+        rest = np.ctypeslib.as_array(tv.rest, shape=(tv.n_verts, 4)).copy() if bool(tv.rest) else None
         yield dict(n_slots=tv.n_slots, n_owned=tv.n_owned, s_pad=sp, n_verts=tv.n_verts, n_excl=tv.n_excl,
-                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet, inc=inc, inc_off=inc_off)
+                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet, inc=inc, inc_off=inc_off, rest=rest)
 
 
 def finish_lists(ts):
@@ -105,7 +106,15 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         nb = tok // 12
         assert np.array_equal(tok % 12, (nb >> 3) & 3), "token = 12 * idx + ((idx >> 3) & 3)"
         assert np.all((pl[2] >> 31) == 0) and np.all(((pl[3] >> 15) & 1) == 0) and np.all((pl[3] >> 31) == 0)
-        dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
+        if T["rest"] is None:
+            dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
+        else:                                    # rebuild_dminv plan: Dm^-1 from the tile's rest positions (exact here)
+            assert pl.shape[0] == 4 and np.all(T["rest"][:, 3] == 0)
+            R = T["rest"][:, :3].astype(np.float64)[lv]                      # [sp,4,3]
+            Dm = np.stack([R[:, 1] - R[:, 0], R[:, 2] - R[:, 0], R[:, 3] - R[:, 0]], axis=2)
+            real = T["slot_tet"] >= 0
+            dminv = np.zeros((sp, 3, 3))
+            dminv[real] = np.linalg.inv(Dm[real])
         assert owned.sum() == T["n_owned"]
         xs = x[T["gvid"]]
         p = xs[lv]                                            # [sp,4,3]
@@ -132,7 +141,7 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         self_idx = perm                        # LDS record of every slot
         missing = nb == self_idx[:, None]
         assert nb.max() < sp, "no neighbour field may point at the zero slot any more"
-        if pl.shape[0] == 13:                 # uniform umbrella: 4 * own - sum of the four (a missing face reads own)
+        if pl.shape[0] in (13, 4):            # uniform umbrella: 4 * own - sum of the four (a missing face reads own)
             wd = 4.0 * np.ones(sp)
             wr = wc = -np.ones((sp, 4))
         else:                                 # explicit element operator: L[e,e], L[e,n_k], L[n_k,e]

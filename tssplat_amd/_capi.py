@@ -35,6 +35,7 @@ class Options(C.Structure):
         ("num_threads", C.c_int32),
         ("debug_shuffle", C.c_int32),
         ("slots_per_thread", C.c_int32),
+        ("rebuild_dminv", C.c_int32),
     ]
 
 
@@ -56,7 +57,7 @@ class TileView(C.Structure):
         ("n_slots", C.c_int32), ("n_owned", C.c_int32), ("s_pad", C.c_int32), ("n_verts", C.c_int32),
         ("n_excl", C.c_int32), ("stage_off", C.c_int64), ("n_inc4", C.c_int32),
         ("planes", C.POINTER(C.c_uint32)), ("inc", C.POINTER(C.c_uint16)), ("inc_off", C.POINTER(C.c_uint16)),
-        ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)),
+        ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)), ("rest", C.POINTER(C.c_float)),
     ]
 
 

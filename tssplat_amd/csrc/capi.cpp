@@ -125,7 +125,7 @@ int to_device(tsamd_handle *h, int device)
     if ((rc = upload(h->d_energy_scratch, nullptr, 1, h->device_bytes))) return rc;
     TSAMD_HIP(hipMemset(h->d_terms, 0, 2 * sizeof(double)));
     {
-        const int32_t lds_p = int32_t(tsamd::tile_lds_bytes((P.max_slots + 3) & ~3, P.max_verts));
+        const int32_t lds_p = int32_t(tsamd::tile_lds_bytes((P.max_slots + 3) & ~3, P.max_verts, P.n_planes == tsamd::kPlanesRebuild));
         TSAMD_HIP(tsamd::configure_kernels(std::max(P.lds_bytes, lds_p <= 160 * 1024 ? lds_p : P.lds_bytes)));
     }
     return TSAMD_OK;
@@ -154,6 +154,9 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.shuffle = opt.debug_shuffle & 1;
     po.conflict_aware = (opt.debug_shuffle & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware ordering off
     if (opt.slots_per_thread == 2 || opt.slots_per_thread == 4) po.slots_per_thread = opt.slots_per_thread;
+    po.rebuild_dminv = opt.rebuild_dminv ? 1 : 0;
+    if (po.rebuild_dminv && po.slots_per_thread != 2)
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "rebuild_dminv needs slots_per_thread = 2");
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;
@@ -209,6 +212,7 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.lds_bytes = h->plan.lds_bytes;
     a.spt = h->plan.spt;
     a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
+    a.rebuild = h->plan.n_planes == tsamd::kPlanesRebuild;
     a.dbg = h->dbg;
     a.clk = h->d_clk;
     a.x = x;
@@ -312,6 +316,10 @@ int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out)
     out->inc_off = out->inc + 4 * size_t(d.n_inc4);
     out->gvid = P.gvid.data() + d.vert_off;
     out->slot_tet = P.slot_tet.data() + P.slot_base[size_t(tile)];
+    out->rest = P.n_planes == tsamd::kPlanesRebuild
+                    ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(out->planes) +
+                                                      tsamd::tile_rest_offset(P.n_planes, d.s_pad, d.n_inc4, d.n_verts))
+                    : nullptr;
     return TSAMD_OK;
 }
 

@@ -94,6 +94,33 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
             F[3 * i + j] = Ds[3 * i + 0] * dm[j][p] + Ds[3 * i + 1] * dm[3 + j][p] + Ds[3 * i + 2] * dm[6 + j][p];
 }
 
+// Dm^-1 of one slot from the staged REST positions (rebuild_dminv plans, plan.h: kPlanesRebuild): Dm has the rest
+// edges x1-x0, x2-x0, x3-x0 as columns, its inverse is cofactor^T / det -- the formula plan.cpp evaluates in double
+// for the streamed planes, here in fp32 (1 / det through v_rcp_f32 and one Newton step).  dm[3 i + k][p] = Dm^-1[i][k].
+template <class VF>
+__device__ __forceinline__ void rebuild_dminv(const unsigned char *rs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+                                              VF *dm, int p)
+{
+    const v4u r0 = *reinterpret_cast<const v4u *>(rs + o0), r1 = *reinterpret_cast<const v4u *>(rs + o1),
+              r2 = *reinterpret_cast<const v4u *>(rs + o2), r3 = *reinterpret_cast<const v4u *>(rs + o3);
+    asm volatile("" : : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+    const float x0 = __uint_as_float(r0.x), y0 = __uint_as_float(r0.y), z0 = __uint_as_float(r0.z);
+    // D[3 i + k] = coordinate i of edge k
+    const float D[9] = {__uint_as_float(r1.x) - x0, __uint_as_float(r2.x) - x0, __uint_as_float(r3.x) - x0,
+                        __uint_as_float(r1.y) - y0, __uint_as_float(r2.y) - y0, __uint_as_float(r3.y) - y0,
+                        __uint_as_float(r1.z) - z0, __uint_as_float(r2.z) - z0, __uint_as_float(r3.z) - z0};
+    float C[9];
+    cof3(D, C);
+    const float det = D[0] * C[0] + D[1] * C[1] + D[2] * C[2];
+    float r = __builtin_amdgcn_rcpf(det);
+    r = __builtin_fmaf(__builtin_fmaf(-det, r, 1.f), r, r);
+    r = det != 0.f ? r : 0.f;   // padding slots (all four vertices = vertex 0): Dm = 0, nothing reads their records
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dm[3 * i + k][p] = C[3 * k + i] * r;
+}
+
 // One 48-byte LDS record (plan.h: record_token) = [tail quad | entries 0..3 | entries 4..7] holds F, later H, later
 // the 4 x 3 vertex forces.  A record is named by the byte address `t` of its ninth matrix entry, which sits in the
 // tail quad at a dword that rotates with bits 3-4 of the record index (at a fixed position the 48-byte stride
@@ -225,7 +252,7 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
 // prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
 // within noise: DESIGN.md section 4.)
-template <bool WITH_GRAD, int SPT, bool WEIGHTED>
+template <bool WITH_GRAD, int SPT, bool WEIGHTED, bool REBUILD>
 __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
 {
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
@@ -238,6 +265,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #else
     constexpr bool kReload = SPT > 2;
 #endif
+    static_assert(!(REBUILD && (WEIGHTED || kReload)), "rebuild_dminv is built for 2 slots per lane and the built-in operator");
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
@@ -249,7 +277,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     const auto g_stage = as_global(a.stage);
     const auto g_partials = as_global(a.partials);
     unsigned char *xs = smem + 48 * SA;
-    double *red = reinterpret_cast<double *>(xs + 16 * VP);
+    double *red = reinterpret_cast<double *>(xs + (REBUILD ? 32 : 16) * VP);
     const int nq = td.s_pad / SPT;
     const uint32_t ZS = uint32_t(td.s_pad);
     const bool active = tid < nq;
@@ -268,8 +296,19 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     VF dm[9];
+    constexpr int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? kPlanesWeighted : kPlanes);
+    // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
+    unsigned char *rs = xs + 16 * VP;
+    const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
+        reinterpret_cast<const GLOBAL_AS unsigned char *>(pl) +
+        ((size_t(kBasePlanes) * td.s_pad * 4 + size_t(td.n_inc4) * 8 + 2 * (size_t(td.n_verts) + 1) + 15) & ~size_t(15)));
+    v4f rest0 = v4f{0.f, 0.f, 0.f, 0.f};
+    if (REBUILD) {
+        rest0 = g_rest[tid < td.n_verts ? tid : 0];
+    } else {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+    }
     // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
     // weights for pass 3 replace them after pass 2
     VF wd, wk[4];
@@ -286,15 +325,17 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     if (tid < td.n_verts) {
         const size_t gv = size_t(gv0) * 3;
         reinterpret_cast<float4 *>(xs)[tid] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+        if (REBUILD) reinterpret_cast<v4f *>(rs)[tid] = rest0;
     }
     for (int v = tid + nthr; v < td.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
         const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
         reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+        if (REBUILD) reinterpret_cast<v4f *>(rs)[v] = g_rest[v];
     }
     __syncthreads();
     STAMP(1);
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
-        float chk = dm[0][0] + dm[4][1] + dm[8][SPT - 1] + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
+        float chk = (REBUILD ? rest0.x : dm[0][0] + dm[4][1] + dm[8][SPT - 1]) + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
                     reinterpret_cast<float *>(xs)[tid % td.n_verts];
         if (chk == 12345.678f) g_partials[0] = chk;
         return;
@@ -319,6 +360,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
             const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
+            if (REBUILD) rebuild_dminv(rs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p);
             float F[9];
             slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
             const float J = det3(F);
@@ -401,7 +443,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         // and the odd chunks), the others one lane (plan.h: vertex_two_lane_count): every vertex is served in one
         // round.  Each lane fetches its first kPre chunks now so that their HBM latency hides behind pass 3.
         constexpr int kPre = 3;
-        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + (WEIGHTED ? kPlanesWeighted : kPlanes) * td.s_pad);
+        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kBasePlanes * td.s_pad);
         const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
         const uint32_t pad16 = (ZS << 2) | 1u;
         int pc0 = 0, pc1 = 0;
@@ -598,7 +640,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 }
 
 
-template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false>
+template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false, bool REBUILD = false>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -614,7 +656,7 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     // run-time check here costs more than it looks: a trap in the prologue turns the descriptor loads into vector loads
     // and their 12 dwords, and every address derived from them, into VGPRs -- measured +26 VGPRs.)
     const TileDesc td0 = a.tiles[tile];
-    tile_body<WITH_GRAD, SPT, WEIGHTED>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
+    tile_body<WITH_GRAD, SPT, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
 }
 
 struct FinishArgs {
@@ -858,7 +900,12 @@ hipError_t configure_kernels(int lds_bytes)
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, true>)};
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, true>),
+                         // rebuild_dminv plans (2 slots per lane)
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, false, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6, false, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, false, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, false, true>)};
     for (const void *fn : fns) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
@@ -913,6 +960,14 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
                 if (e.grad) TSAMD_LAUNCH_W(true, 4); else TSAMD_LAUNCH_W(false, 4);
             }
 #undef TSAMD_LAUNCH_W
+        } else if (e.rebuild) {
+#define TSAMD_LAUNCH_R(G, B, W) hipLaunchKernelGGL((tile_energy_kernel<G, B, 2, W, false, true>), grid, block, size_t(lds), stream, k)
+            if (two_per_cu) {
+                if (e.grad) TSAMD_LAUNCH_R(true, 768, 6); else TSAMD_LAUNCH_R(false, 768, 6);
+            } else {
+                if (e.grad) TSAMD_LAUNCH_R(true, 1024, 4); else TSAMD_LAUNCH_R(false, 1024, 4);
+            }
+#undef TSAMD_LAUNCH_R
         } else if (e.spt == 2 && two_per_cu) {
             if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
         } else if (e.spt == 2) {

@@ -154,10 +154,11 @@ struct Scratch {
 struct Limits {
     int64_t budget;
     int64_t max_spad;
+    bool rebuild = false;
     bool fits(int64_t n_slots, int64_t n_verts) const
     {
         const int64_t sp = (n_slots + 3) & ~int64_t(3);
-        return sp <= max_spad && n_verts <= kMaxTileVerts && tile_lds_bytes(sp, n_verts) <= budget;
+        return sp <= max_spad && n_verts <= kMaxTileVerts && tile_lds_bytes(sp, n_verts, rebuild) <= budget;
     }
 };
 
@@ -323,7 +324,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 80 * 1024;
     const int spt = opt.slots_per_thread == 4 ? 4 : 2;
     lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 2728);  // record tokens (12 idx + rot) are 15-bit fields
-    if (lim.budget < tile_lds_bytes(8, 8)) {
+    lim.rebuild = opt.rebuild_dminv != 0 && op == nullptr;
+    if (lim.budget < tile_lds_bytes(8, 8, lim.rebuild)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
     }
@@ -377,6 +379,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         for (int64_t i = 0; i < 4 * m; ++i) P.op_w[size_t(i)] = float(w[size_t(i)]);   // reference rounds its matrices
     }
     const bool weighted = op != nullptr;
+    const bool rebuild = lim.rebuild;
+    if (rebuild) P.n_planes = kPlanesRebuild;
     const int n_planes = P.n_planes;
 
     // ---- connected components over face adjacency (each tet-sphere is one) ----
@@ -472,7 +476,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     }
     // LDS: 48 B per slot + 16 B per vertex at ~0.27 vertices per slot
-    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / 53);
+    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / (rebuild ? 58 : 53));
     int64_t target = opt.target_owned > 0 ? opt.target_owned : int64_t(0.70 * double(s_cap));
     target = std::max<int64_t>(1, target);
 
@@ -615,7 +619,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             err = "tile incidence list too long for 16-bit chunk offsets";
             return ERR_TILING;
         }
-        blob_bytes += (int64_t(n_planes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1) + 127) &
+        blob_bytes += ((rebuild ? tile_rest_offset(n_planes, d.s_pad, d.n_inc4, d.n_verts) + 16 * int64_t(d.n_verts)
+                                : int64_t(n_planes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1)) + 127) &
                       ~int64_t(127);
         vert_off += d.n_verts;
         stage_off += d.n_verts - d.n_excl;
@@ -624,7 +629,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         P.total_slots += d.n_slots;
         P.max_slots = std::max(P.max_slots, d.n_slots);
         P.max_verts = std::max(P.max_verts, d.n_verts);
-        P.lds_bytes = std::max<int32_t>(P.lds_bytes, int32_t(tile_lds_bytes(d.s_pad, d.n_verts)));
+        P.lds_bytes = std::max<int32_t>(P.lds_bytes, int32_t(tile_lds_bytes(d.s_pad, d.n_verts, rebuild)));
         max_quads = std::max(max_quads, d.s_pad / spt);
         if (vert_off >= (int64_t(1) << 31)) {
             err = "too many tile vertices for 32-bit offsets";
@@ -746,11 +751,12 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     singular.store(1);
                     continue;
                 }
-                for (int i = 0; i < 3; ++i)
-                    for (int k = 0; k < 3; ++k) {
-                        float v = float(Cf[3 * k + i] / det);  // inverse = cofactor^T / det
-                        std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
-                    }
+                if (!rebuild)
+                    for (int i = 0; i < 3; ++i)
+                        for (int k = 0; k < 3; ++k) {
+                            float v = float(Cf[3 * k + i] / det);  // inverse = cofactor^T / det
+                            std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
+                        }
             }
             // ---- LDS bank-conflict-aware neighbour order ----
             // A wave reads neighbour k of 16 lanes' tets with one ds_read_b128 per 16-lane group; two lanes
@@ -817,6 +823,17 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                     chunk += (cnt[size_t(v)] + 3) / 4;
                 }
                 inc_off[d.n_verts] = uint16_t(chunk);
+                if (rebuild) {   // the tile's rest positions, tile vertex order, one float4 each
+                    float *rp = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(pl) +
+                                                          tile_rest_offset(n_planes, d.s_pad, d.n_inc4, d.n_verts));
+                    for (int32_t v = 0; v < d.n_verts; ++v) {
+                        const int32_t gv = tv[size_t(v)];
+                        rp[4 * v + 0] = rest[3 * size_t(gv) + 0];
+                        rp[4 * v + 1] = rest[3 * size_t(gv) + 1];
+                        rp[4 * v + 2] = rest[3 * size_t(gv) + 2];
+                        rp[4 * v + 3] = 0.f;
+                    }
+                }
                 const uint16_t pad = uint16_t((ZS << 2) | 1u);
                 for (int64_t i = 0; i < 4 * int64_t(d.n_inc4); ++i) inc[i] = pad;
                 for (int32_t sl = 0; sl < d.s_pad; ++sl) {  // slot-major fill => each list is sorted by slot

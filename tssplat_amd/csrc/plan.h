@@ -26,6 +26,8 @@ struct PlanOptions {
     int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
     int slots_per_thread = 2;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
     int conflict_aware = 1;       // order neighbour / incidence entries to dodge LDS bank conflicts
+    int rebuild_dminv = 0;        // 1 = do not stream Dm^-1 (36 of the 52 bytes per slot): keep each tile's REST positions
+                                  // (16 B per tile vertex) and invert Dm in registers, in fp32 (see kPlanesRebuild)
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
@@ -56,6 +58,13 @@ constexpr int kPlanes = 13;
 // (0 where the neighbour is the zero slot).  Without an operator the kernels use the uniform face-adjacency
 // umbrella (diagonal = number of face neighbours, off-diagonals = -1) and these planes do not exist.
 constexpr int kPlanesWeighted = 22;
+// Plans built with rebuild_dminv carry only the four index planes (16 bytes per slot instead of 52) and, behind the
+// incidence offsets (16-byte aligned), one float4 per tile vertex with its REST position; the kernels stage those next
+// to the current positions and rebuild Dm^-1 = cofactor^T / det per slot in fp32 registers.  This is NOT bit-identical
+// to the streamed operator (built in double and rounded to fp32 like the reference's matrices, tet_spheres.cpp:43-45):
+// entries differ by <= 2.8e-7 relative (mean 2.7e-8) against 5.9e-8 (mean 1.1e-8) for the rounding itself, and the
+// gradient moves by ~7e-8 relative (profiles/r02_experiments.md).  Not combined with an explicit operator.
+constexpr int kPlanesRebuild = 4;
 // Index planes, two 16-bit fields per dword:
 //   lv01 = (16 * v0 | owned << 15) | (16 * v1) << 16      vertex ids pre-multiplied to byte offsets
 //   lv23 = (16 * v2)               | (16 * v3) << 16      into the staged float4 positions
@@ -93,11 +102,17 @@ inline int32_t lds_index(int32_t slot, int32_t nq, int32_t spt) { return (slot %
 // LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices:
 // 48 B per slot (F as 9 floats + 3 pad, later H, later the 4 x 3 vertex forces), + the zero slot,
 // 16 B per staged vertex position, 256 B of reduction scratch.
-inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts)
+inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts, bool rebuild_dminv = false)
 {
     const int64_t sa = s_pad + 4;
     const int64_t vp = (n_verts + 3) & ~int64_t(3);
-    return 48 * sa + 16 * vp + 256;
+    return 48 * sa + (rebuild_dminv ? 32 : 16) * vp + 256;   // (+ the staged rest positions)
+}
+
+// Byte offset, inside a tile's blob, of the float4 rest positions of a rebuild_dminv plan.
+inline int64_t tile_rest_offset(int64_t n_planes, int64_t s_pad, int64_t n_inc4, int64_t n_verts)
+{
+    return (n_planes * s_pad * 4 + n_inc4 * 8 + 2 * (n_verts + 1) + 15) & ~int64_t(15);
 }
 
 struct Plan {

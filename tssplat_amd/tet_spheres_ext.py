@@ -51,6 +51,8 @@ __all__ = ["TetSpheres", "forward", "backward", "random_x", "grad_limit"]
 
 _lib = _capi.load()          # fail loudly at import if the HIP library is absent
 CPU_ENERGY = os.environ.get("TSSPLAT_AMD_CPU_ENERGY", "0") == "1"   # read once: os.environ lookups are slow
+# default of TetSpheres(rebuild_dminv=None): stream the exactly rounded Dm^-1 planes (0) or rebuild it in registers (1)
+REBUILD_DMINV = os.environ.get("TSSPLAT_AMD_REBUILD_DMINV", "0") == "1"
 print("initializing")         # tet_spheres.cpp:19 prints this at module import
 
 
@@ -88,7 +90,7 @@ class TetSpheres:
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
                  balance_slots: bool = True, num_threads: int = 0, debug_shuffle: int = 0,
-                 slots_per_thread: int = 0, operator=None):
+                 slots_per_thread: int = 0, operator=None, rebuild_dminv: bool | None = None):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
         self._cache = None
@@ -108,7 +110,9 @@ class TetSpheres:
                                   host_only=int(host_only), lds_budget_bytes=lds_budget_bytes,
                                   max_threads=max_threads, target_owned=target_owned,
                                   balance_slots=int(balance_slots), num_threads=num_threads,
-                                  debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread)
+                                  debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread,
+                                  rebuild_dminv=int(REBUILD_DMINV if rebuild_dminv is None else rebuild_dminv)
+                                  if operator is None and slots_per_thread in (0, 2) else 0)
         if isinstance(vertices, (str, os.PathLike)) and elements is None:
             if operator is not None:
                 raise TypeError("operator= needs the (vertices, elements) constructor")
