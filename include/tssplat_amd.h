@@ -29,8 +29,10 @@
  * synchronises the host with the device except tsamd_create / tsamd_destroy /
  * tsamd_read_energy_terms.  Every function returns 0 on success and a nonzero
  * tsamd_status otherwise; the message is available from tsamd_last_error()
- * (thread-local).  A handle is not re-entrant: one evaluation at a time per
- * handle (same rule as the reference's per-object scratch, tet_spheres.h:36-40).
+ * (thread-local).  A handle is not re-entrant and is single-stream: its staging rows, per-tile partials and
+ * energy terms are per-handle scratch, so evaluations of ONE handle must be ordered (one stream, or events between
+ * streams); different handles are independent (same rule as the reference's per-object scratch,
+ * tet_spheres.h:36-40).
  */
 #ifndef TSSPLAT_AMD_H
 #define TSSPLAT_AMD_H

@@ -228,6 +228,10 @@ def test_autograd_surface_and_cache(ext):
     # CPU grad_output (the reference hands a CPU 0-dim tensor, tet_spheres_cuda.cu:194,257)
     g_cpu_go = ext_backward_cpu_go(mod, x, c1, c2)
     assert torch.allclose(g_cpu_go, g_cached, rtol=1e-5, atol=1e-6 * float(g_cached.abs().max()))
+    # under torch.no_grad() (logging, validation) no gradient pass runs and nothing is cached
+    with torch.no_grad():
+        e_ng = mod(x, 1200, c1, c2)
+    assert mod.tet_sp._cache is None and abs(float(e_ng) - E) <= 1e-5 * abs(E)
     # reference CPU-energy convention on request
     from tssplat_amd import tet_spheres_ext as _ext
     _ext.CPU_ENERGY = True
@@ -498,3 +502,27 @@ def test_graph_replay_equals_eager(ext):
         # the eager route scales by c1 in the kernel and by 0.75 in tsamd_scale)
         assert torch.allclose(g_g, x.grad, rtol=3e-7, atol=0), it
     assert sorted(graphed._graphs) == [2, 4]
+
+
+def test_compiled_c_consumer_on_device(tmp_path):
+    """tests/c/abi_device.c: a compiled C99 program -- no Python, torch or ctypes between it and the library -- drives
+    the device entry points of include/tssplat_amd.h and checks them against the C oracle."""
+    import subprocess
+    from oracle import c_oracle
+    from tssplat_amd import _capi
+    _capi.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib, ora = _capi.lib_path(), c_oracle.build()
+    hip = "/opt/rocm/lib"
+    exe = tmp_path / "abi_device"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-I", os.path.join(root, "include"),
+           "-I", "/opt/rocm/include", os.path.join(root, "tests", "c", "abi_device.c"), "-o", str(exe),
+           "-L", os.path.dirname(lib), "-ltssplat_amd", "-L", os.path.dirname(ora), "-ltet_energy_oracle",
+           "-L", hip, "-lamdhip64", "-lm", f"-Wl,-rpath,{os.path.dirname(lib)}", f"-Wl,-rpath,{os.path.dirname(ora)}",
+           f"-Wl,-rpath,{hip}"]
+    built = subprocess.run(cmd, capture_output=True, text=True)
+    assert built.returncode == 0, built.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, f"exit {out.returncode}: {out.stdout[-2000:]} {out.stderr[-2000:]}"
+    assert "abi device ok" in out.stdout

@@ -890,6 +890,12 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
 
 hipError_t configure_kernels(int lds_bytes)
 {
+    // hipFuncAttributeMaxDynamicSharedMemorySize is per function, i.e. per process and device -- not per handle: only
+    // ever raise it, or a handle with small tiles would lower the limit under an earlier handle with large ones
+    static int configured[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds_bytes <= configured[dev]) return hipSuccess;
     const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4>),
@@ -910,6 +916,7 @@ hipError_t configure_kernels(int lds_bytes)
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
+    configured[dev] = lds_bytes;
     return hipSuccess;
 }
 

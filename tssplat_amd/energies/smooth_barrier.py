@@ -55,7 +55,7 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
         f_flat = np.asarray(tet_f).flatten().astype(np.int32)        # smooth_barrier.py:39
         self.tet_sp = tet_spheres_ext.TetSpheres(v_flat, f_flat, **tet_spheres_kwargs)
         self.FLAGS = FLAGS
-        self.smooth_eng_func = SmoothnessBarrierFunc()
+        self.smooth_eng_func = SmoothnessBarrierFunc          # (the reference instantiates the Function, smooth_barrier.py:45; torch deprecates that)
 
     def coeff_scheduler(self, it):
         """x1 at it=0 rising to x16 from it=1200 on (smooth_barrier.py:47-58)."""
@@ -66,4 +66,11 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
 
     def forward(self, x, it, c1, c2):
         order = 4 if it > self.FLAGS.increase_order_iter else 2      # smooth_barrier.py:61-63
-        return self.smooth_eng_func.apply(x, self.tet_sp, c1, c2, order)
+        if not torch.is_grad_enabled():
+            # logging / validation under torch.no_grad(): energy only -- no fused gradient pass, nothing left in the cache
+            fuse, self.tet_sp.fuse_forward_backward = self.tet_sp.fuse_forward_backward, False
+            try:
+                return tet_spheres_ext.forward(x, self.tet_sp, c1, c2, order)
+            finally:
+                self.tet_sp.fuse_forward_backward = fuse
+        return SmoothnessBarrierFunc.apply(x, self.tet_sp, c1, c2, order)

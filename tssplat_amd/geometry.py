@@ -19,6 +19,8 @@ import ctypes as C
 from typing import Optional
 
 import numpy as np
+import weakref
+
 import torch
 
 from . import _capi
@@ -137,15 +139,24 @@ _OPS_CACHE: dict = {}
 
 def _ops_for(surface_vid: torch.Tensor, surface_f: torch.Tensor, n_tet_vertices: int) -> SurfaceOps:
     """The reference rebuilds TetMeshGeometryForwardData every iteration from the same index tensors
-    (tetmesh_geometry.py:190-192); the topology handle is cached on their storage so that only the first
-    iteration pays for the host-side incidence build."""
-    key = (surface_vid.data_ptr(), surface_f.data_ptr(), tuple(surface_vid.shape), tuple(surface_f.shape),
-           int(n_tet_vertices), surface_vid._version, surface_f._version)
-    ops = _OPS_CACHE.get(key)
-    if ops is None:
-        if len(_OPS_CACHE) > 8:
-            _OPS_CACHE.clear()
-        ops = _OPS_CACHE[key] = SurfaceOps(surface_vid, surface_f, n_tet_vertices)
+    (tetmesh_geometry.py:190-192); the topology handle is cached per pair of index tensors so that only the first
+    iteration pays for the host-side incidence build.  An entry is valid only while BOTH tensors it was built from
+    are alive and unmodified: it holds weak references to them and checks identity, version and device, so a freed
+    tensor whose address a new one happens to reuse (TetMeshGeometry.reset()) can never be served the old topology."""
+    key = (surface_vid.data_ptr(), surface_f.data_ptr(), str(surface_vid.device), tuple(surface_vid.shape),
+           tuple(surface_f.shape), int(n_tet_vertices))
+    hit = _OPS_CACHE.get(key)
+    if hit is not None:
+        ops, ref_v, ref_f, ver = hit
+        if ref_v() is surface_vid and ref_f() is surface_f and ver == (surface_vid._version, surface_f._version):
+            return ops
+        del _OPS_CACHE[key]
+    for k in [k for k, (_, rv, rf, _) in _OPS_CACHE.items() if rv() is None or rf() is None]:
+        del _OPS_CACHE[k]                                  # entries whose tensors are gone release their device memory
+    if len(_OPS_CACHE) > 8:
+        _OPS_CACHE.clear()
+    ops = SurfaceOps(surface_vid, surface_f, n_tet_vertices)
+    _OPS_CACHE[key] = (ops, weakref.ref(surface_vid), weakref.ref(surface_f), (surface_vid._version, surface_f._version))
     return ops
 
 

@@ -24,11 +24,15 @@ Deliberate differences from the reference (all listed in DESIGN.md):
   tet_spheres_cuda.cu:154,185,194).  Set ``TSSPLAT_AMD_CPU_ENERGY=1`` before import
   (or ``tet_spheres_ext.CPU_ENERGY = True``) for the reference's CPU return.  ``backward`` accepts ``gradH`` on either device and
   applies it on the GPU without ``.item()`` (contrast .cu:257).
-* when ``input.requires_grad`` the forward call evaluates energy *and*
-  gradient in one fused pass and keeps the unscaled gradient on the
-  ``TetSpheres`` object; the matching ``backward`` call only multiplies it by
-  ``gradH``.  The cache key is ``(data_ptr, _version, shape, c1, c2, order)``;
-  any miss recomputes.  The reference recomputes ``G x`` in backward (.cu:221).
+* when ``input.requires_grad`` the forward call
+  evaluates energy *and* gradient in one fused pass and keeps the unscaled
+  gradient on the ``TetSpheres`` object; the matching ``backward`` call only
+  multiplies it by ``gradH``.  The cache key is ``(data_ptr, _version, shape, c1,
+  c2, order)``; any miss recomputes, and every ``forward`` replaces or drops the
+  entry.  The key cannot see writes that bypass torch's version counter (``.data``
+  ops, the raw-pointer ``AdamUniform`` step): the cache assumes that ``backward``
+  follows ITS ``forward`` with no such write in between, which is what
+  ``loss.backward()`` does.  The reference recomputes ``G x`` in backward (.cu:221).
 * a 2-D vertex/element array makes the reference print to stderr and hand back
   an empty, unusable object (tet_spheres.cpp:238-250); we print the same line
   and return an object whose use raises ``RuntimeError`` instead of crashing.
@@ -218,12 +222,15 @@ def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, orde
     energy = torch.empty((), dtype=torch.float32, device=x.device)
     stream = _stream_ptr(x.device)
     # (no torch.cuda.device() guard: the library switches to the handle's device itself)
+    # (grad mode cannot be consulted here: inside autograd.Function.forward it is always off.  Callers that evaluate
+    # under torch.no_grad() switch the fusion off themselves -- SmoothnessBarrierEnergy.forward does.)
     if input.requires_grad and tet_sph.fuse_forward_backward:
         g = torch.empty_like(x)
         _capi.check(_lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, int(order), stream,
                                                 energy.data_ptr(), g.data_ptr()))
         tet_sph._cache = (_cache_key(input, c1, c2, order), g)
     else:
+        tet_sph._cache = None
         _capi.check(_lib.tsamd_forward(h, x.data_ptr(), c1, c2, int(order), stream, energy.data_ptr()))
     if CPU_ENERGY:
         return energy.cpu()                             # the reference's convention, .cu:194
