@@ -206,6 +206,24 @@ __device__ __forceinline__ Mat9 operator_gather(const unsigned char *lds, const 
     return acc;
 }
 
+// Sum over the 64 lanes of a wave, in a fixed order, returned in every lane.  DPP adds inside each row of 16 lanes
+// (no LDS traffic, a few cycles each), then the four row sums through v_readlane.  `__shfl_down` is ds_bpermute on
+// gfx950: twelve dependent LDS round trips for the two energy terms, ~2 000 cycles at the very end of every tile,
+// where nothing of the workgroup is left to hide them.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define TSAMD_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
+    v += TSAMD_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += TSAMD_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += TSAMD_DPP(v, 0x124);   // row_ror:4
+    v += TSAMD_DPP(v, 0x128);   // row_ror:8  -> every lane holds the sum of its row of 16
+#undef TSAMD_DPP
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)),
+                r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 struct KernelArgs {
     const TileDesc *tiles;
     const uint8_t *blob;
@@ -616,11 +634,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 
     STAMP(8);  // vertex gather + stores done (this wave)
     // ---- deterministic block reduction of the two energy terms (fixed order; doubles across waves) ----
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        e_s += __shfl_down(e_s, off, kWave);
-        e_b += __shfl_down(e_b, off, kWave);
-    }
+    e_s = wave_sum(e_s);
+    e_b = wave_sum(e_b);
     const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
     if (lane == 0) {
         red[2 * wave] = double(e_s);
