@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--shuffle", action="store_true")
     ap.add_argument("--spt", type=int, default=0)
     ap.add_argument("--no-conflict-aware", action="store_true")
+    ap.add_argument("--rebuild-dminv", action="store_true")
     args = ap.parse_args()
     # the production library has the switches compiled out; build / select the ablation variant
     from tssplat_amd import _build
@@ -54,7 +55,8 @@ def main():
     sc = scenes.make_scene(args.scene, args.spheres)
     ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), max_threads=args.max_threads,
                       lds_budget_bytes=args.lds_budget, target_owned=args.target_owned,
-                      balance_slots=not args.no_balance, debug_shuffle=int(args.shuffle) | (2 if args.no_conflict_aware else 0), slots_per_thread=args.spt)
+                      balance_slots=not args.no_balance, debug_shuffle=int(args.shuffle) | (2 if args.no_conflict_aware else 0), slots_per_thread=args.spt,
+                      rebuild_dminv=args.rebuild_dminv)
     info = ts.plan_info()
     x = torch.from_numpy(scenes.deform(sc, args.sigma)).cuda()
     g = torch.empty_like(x)

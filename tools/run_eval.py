@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--max-threads", type=int, default=0)
     ap.add_argument("--lds-budget", type=int, default=0)
     ap.add_argument("--spt", type=int, default=0)
+    ap.add_argument("--rebuild-dminv", type=int, default=0)
     args = ap.parse_args()
     import torch
     from tssplat_amd import _capi, scenes, tet_spheres_ext as T
     lib = _capi.load()
     sc = scenes.make_scene(args.scene, args.spheres)
     ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), debug_shuffle=args.debug_shuffle, max_threads=args.max_threads,
-                      lds_budget_bytes=args.lds_budget, slots_per_thread=args.spt)
+                      lds_budget_bytes=args.lds_budget, slots_per_thread=args.spt, rebuild_dminv=bool(args.rebuild_dminv))
     x = torch.from_numpy(scenes.deform(sc, args.sigma)).cuda()
     g = torch.empty_like(x)
     e = torch.empty((), device="cuda")

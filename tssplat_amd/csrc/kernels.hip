@@ -655,6 +655,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 }
 
 
+
 template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false, bool REBUILD = false>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
