@@ -350,7 +350,8 @@ def _run_rank(args, stdout_fd: int) -> None:
         for name, fn in (("graph", step_graph), ("eager", step_eager)):
             preheat()
             probe[name] = timed(fn, 10, 3)[0] / 10
-        pick = torch.tensor([0 if probe["graph"] <= probe["eager"] else 1], device=dev)
+        # (replay only where it clearly wins: on the 21 M-tet scene the two are within the probe's noise)
+        pick = torch.tensor([0 if probe["graph"] <= 0.95 * probe["eager"] else 1], device=dev)
         if world > 1:
             dist.broadcast(pick, src=0)
         launch_mode = "graph" if int(pick.item()) == 0 else "eager"
