@@ -1,11 +1,12 @@
 // gfx950 (MI355X / CDNA4) kernels for the tet-sphere geometry energy.
 //
-// One workgroup evaluates one *tile*: a cluster of up to ~3 800 tets (owned +
-// one-ring face halo) whose deformation gradients F fit the CU's 160 KiB LDS.
-// Per evaluation the tile's 13 dword planes (16-bit local indices + fp32
-// Dm^-1, 52 B per slot) stream from HBM exactly once with perfectly coalesced
-// 16 B/lane loads; F, L F, L^T L F and the vertex accumulation never leave the
-// CU.  No MFMA: 3x3 algebra at ~4 flop/B is bandwidth bound.
+// One workgroup evaluates one *tile*: a cluster of tets (owned + one-ring face halo; ~1 500 slots at the default
+// 768 threads x 2 slots per lane and <= 80 KiB of LDS, two workgroups per CU; up to 2 728 slots with one 160 KiB
+// workgroup) whose deformation gradients F fit the LDS.  Per evaluation the tile's dword planes (16-bit local
+// vertex offsets, 15-bit record tokens of the face neighbours, fp32 Dm^-1: 13 planes = 52 B per slot; 22 with an
+// explicit element operator, 4 with rebuild_dminv -- plan.h) stream from HBM exactly once, coalesced; F, L F,
+// L^T L F and the vertex accumulation never leave the CU.  No MFMA: 3x3 algebra at ~4 flop/B; the kernel is bound
+// by VALU issue + LDS data movement per slot, not by HBM (profiles/r02_experiments.md).
 //
 // What each stage stands for in the reference
 // (/root/reference/tssplat_ext/tet_spheres/tet_spheres_cuda.cu):
@@ -134,7 +135,8 @@ struct Mat9 {
 };
 
 // LDS accesses by absolute byte address.  The kernels' only LDS object is the dynamic array, which starts at LDS
-// address 0 (checked at kernel entry); addressing it as `smem + offset` makes the compiler add the array's link-time
+// address 0 (asserted on the host: the kernels declare no static __shared__ object, and a device-side check in
+// the prologue costs 26 VGPRs, see profiles/r02_experiments.md); addressing it as `smem + offset` makes the compiler add the array's link-time
 // address -- a literal 0 -- to every computed offset: one wasted VALU instruction per access in a kernel that is
 // bound by instruction issue.
 #define LDS_AS __attribute__((address_space(3)))

@@ -55,7 +55,7 @@ constexpr int kPlanes = 13;
 //   [13]      L[e, e]
 //   [14..17]  L[e, n_k]   row weights, in the slot's (possibly re-ordered) neighbour order -- pass 2, H = L F
 //   [18..21]  L[n_k, e]   column weights, same order                                     -- pass 3, Q = L^T H
-// (0 where the neighbour is the zero slot).  Without an operator the kernels use the uniform face-adjacency
+// (0 where a face has no neighbour and the token points at the slot itself).  Without an operator the kernels use the uniform face-adjacency
 // umbrella (diagonal = number of face neighbours, off-diagonals = -1) and these planes do not exist.
 constexpr int kPlanesWeighted = 22;
 // Plans built with rebuild_dminv carry only the four index planes (16 bytes per slot instead of 52) and, behind the
