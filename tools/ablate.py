@@ -42,7 +42,10 @@ def main():
     ap.add_argument("--spt", type=int, default=0)
     ap.add_argument("--no-conflict-aware", action="store_true")
     ap.add_argument("--rebuild-dminv", action="store_true")
+    ap.add_argument("--lds-request", type=int, default=0, help="request this much dynamic LDS per workgroup (limits workgroups per CU)")
     args = ap.parse_args()
+    if args.lds_request:
+        os.environ["TSAMD_LDS_REQUEST"] = str(args.lds_request)
     # the production library has the switches compiled out; build / select the ablation variant
     from tssplat_amd import _build
     variant = os.path.join(os.path.dirname(_build.LIB), "libtssplat_amd_ablation.so")

@@ -175,9 +175,16 @@ __device__ __forceinline__ void sub9(Mat9 &acc, const Mat9 &g)
     acc.p8 -= g.p8;
 }
 
-__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, uint32_t t_own, const uint32_t *nb)
+__device__ __forceinline__ Mat9 mat9_of(const float *m)
 {
-    Mat9 acc = load_slot(lds, t_own);
+    Mat9 r;
+    r.p01 = v2f{m[0], m[1]}; r.p23 = v2f{m[2], m[3]}; r.p45 = v2f{m[4], m[5]}; r.p67 = v2f{m[6], m[7]};
+    r.p8 = m[8];
+    return r;
+}
+
+__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 acc, const uint32_t *nb)
+{
     Mat9 g0 = load_slot(lds, nb[0]);
     acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
     acc.p8 *= 4.f;
@@ -286,6 +293,14 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     constexpr bool kReload = SPT > 2;
 #endif
     static_assert(!(REBUILD && (WEIGHTED || kReload)), "rebuild_dminv is built for 2 slots per lane and the built-in operator");
+    // 2 slots per lane: a slot's own F stays in registers from pass 1 to pass 2 instead of being read back from LDS
+    // (-8 LDS cycles per 64 slots, tile kernel -0.9 %).  Keeping the own H for pass 3 as well was measured: both slots
+    // spill 3 dwords, one slot alone gains 0.5 % and nothing on top of the F variant (profiles/r02_experiments.md).
+#ifdef TSAMD_KEEP_OWN
+    constexpr int kKeepF = TSAMD_KEEP_OWN & 1 ? SPT : 0, kKeepH = TSAMD_KEEP_OWN & 2 ? SPT : (TSAMD_KEEP_OWN & 4 ? 1 : 0);
+#else
+    constexpr int kKeepF = SPT == 2 ? SPT : 0, kKeepH = 0;
+#endif
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
@@ -376,6 +391,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
     for (int p = 0; p < SPT; ++p) scal[p] = 0.f;
     float e_b = 0.f, e_s = 0.f;
+    float Fk[kKeepF > 0 ? kKeepF : 1][9];
+#pragma unroll
+    for (int p = 0; p < kKeepF; ++p)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) Fk[p][c] = 0.f;
     if (active) {
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
@@ -383,6 +403,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             if (REBUILD) rebuild_dminv(rs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p);
             float F[9];
             slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
+            if (p < kKeepF) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c) Fk[p][c] = F[c];
+            }
             const float J = det3(F);
             const float Jm = fmaxf(-J, 0.f);
             float pen = 0.f, dpen = 0.f;
@@ -432,7 +456,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
                     h = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
-                    h = laplace_gather(smem, t_own[p], nb);
+                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own[p]), nb);
                 }
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
@@ -502,14 +526,32 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 uint32_t nb[4];
                 neighbours(n01, n23, nb);
                 if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = t_own[p];
+#ifdef TSAMD_DUMMY_LDS   // experiments: marginal cost of LDS reads (conflict-free b128 reads of the own record, results unused)
+                {
+                    v4f dummy;
+#pragma unroll
+                    for (int j = 0; j < TSAMD_DUMMY_LDS; ++j)
+                        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(dummy) : "v"(t_own[p] & ~15u));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(dummy));
+                }
+#endif
                 // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
                 Mat9 q;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
                     q = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
-                    q = laplace_gather(smem, t_own[p], nb);
+                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb);
                 }
+#ifdef TSAMD_DUMMY_VALU  // experiments: marginal cost of VALU instructions (independent FMAs on four accumulators)
+                {
+                    float da[4] = {q.p8, q.p8, q.p8, q.p8};
+#pragma unroll
+                    for (int j = 0; j < TSAMD_DUMMY_VALU; ++j)
+                        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(da[j & 3]) : "v"(s_pen));
+                    asm volatile("" : : "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]));
+                }
+#endif
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (!use_c1) {   // smoothness switched off: only the penalty term is left
 #pragma unroll
@@ -906,8 +948,21 @@ int grid_for(int64_t n, int per_block, int cap)
 
 hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev);
 
+#ifdef TSAMD_ABLATION
+// experiments only: request more dynamic LDS than the tiles need, to limit the workgroups per CU (tools/ablate.py)
+static size_t ablation_lds_request(size_t lds)
+{
+    static const char *s = getenv("TSAMD_LDS_REQUEST");
+    const size_t v = s ? size_t(strtoul(s, nullptr, 10)) : 0;
+    return v > lds ? v : lds;
+}
+#endif
+
 hipError_t configure_kernels(int lds_bytes)
 {
+#ifdef TSAMD_ABLATION
+    lds_bytes = int(ablation_lds_request(size_t(lds_bytes)));
+#endif
     // hipFuncAttributeMaxDynamicSharedMemorySize is per function, i.e. per process and device -- not per handle: only
     // ever raise it, or a handle with small tiles would lower the limit under an earlier handle with large ones
     static int configured[64] = {};
@@ -975,7 +1030,11 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         const bool two_per_cu = e.spt == 2 && e.block_threads <= 768 && e.lds_bytes <= 80 * 1024;
 #define TSAMD_LAUNCH(G, B, S, W) \
     hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(lds), stream, k)
+#ifdef TSAMD_ABLATION
+        const size_t lds = ablation_lds_request(size_t(e.lds_bytes));
+#else
         const size_t lds = size_t(e.lds_bytes);
+#endif
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
         if (e.weighted) {
 #define TSAMD_LAUNCH_W(G, S) hipLaunchKernelGGL((tile_energy_kernel<G, 1024, S, 4, true>), grid, block, size_t(lds), stream, k)
