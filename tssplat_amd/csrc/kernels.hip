@@ -185,6 +185,9 @@ __device__ __forceinline__ Mat9 mat9_of(const float *m)
 
 __device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 acc, const uint32_t *nb)
 {
+#ifdef TSAMD_PRIO   // experiment: waves that are issuing gathers win the arbitration against waves doing algebra
+    __builtin_amdgcn_s_setprio(TSAMD_PRIO);
+#endif
     Mat9 g0 = load_slot(lds, nb[0]);
     acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
     acc.p8 *= 4.f;
@@ -193,6 +196,9 @@ __device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 ac
     g0 = load_slot(lds, nb[2]);
     sub9(acc, g1);
     g1 = load_slot(lds, nb[3]);
+#ifdef TSAMD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     sub9(acc, g0);
     sub9(acc, g1);
     return acc;
