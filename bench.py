@@ -282,7 +282,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     def raw():
         _capi.check(lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, args.order, stream0, e_raw.data_ptr(), g_raw.data_ptr()))
 
-    def preheat(ms=30.0):
+    def preheat(ms=120.0):
         """Continuous GPU work (no host sync inside) so that what follows starts at steady clocks."""
         raw()
         torch.cuda.synchronize(dev)
@@ -290,7 +290,7 @@ def _run_rank(args, stdout_fd: int) -> None:
         raw()
         torch.cuda.synchronize(dev)
         one = max(time.perf_counter() - t, 1e-6)
-        for _ in range(int(min(max(ms * 1e-3 / one, 40), 4000))):
+        for _ in range(int(min(max(ms * 1e-3 / one, 40), 8000))):
             raw()
 
     graphed = None
@@ -382,7 +382,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     preheat()
     torch.cuda.synchronize(dev)
     energy.tet_sp.set_timing(True)
-    for _ in range(args.steps):
+    for _ in range(max(args.steps, 50)):               # (at least 50 launches: a 20-launch average moves by 3 % between runs)
         raw()
     torch.cuda.synchronize(dev)
     tile_ms, finish_ms, n_eval = energy.tet_sp.get_timing()
