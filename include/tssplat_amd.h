@@ -60,8 +60,8 @@ typedef enum tsamd_status {
 typedef struct tsamd_options {
     int32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
-    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU) */
-    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 768                       */
+    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU; 54400 with an explicit operator) */
+    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 768 (512 with an explicit operator) */
     int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto            */
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */

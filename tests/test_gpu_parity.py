@@ -385,7 +385,8 @@ def test_random_tiling_options_on_gpu(ext):
     assert ran >= 10
 
 
-@pytest.mark.parametrize("kind,S,kw", [("kuhn8", 8, {}), ("kuhn19", 2, {}), ("kuhn19", 2, dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840)),
+@pytest.mark.parametrize("kind,S,kw", [("kuhn8", 8, {}), ("kuhn19", 2, {}), ("kuhn19", 2, dict(max_threads=768, lds_budget_bytes=81920)),
+                                       ("kuhn19", 2, dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840)),
                                        ("delaunay3000", 3, {})])
 def test_explicit_operator_parity(ext, kind, S, kw):
     """tsamd_create_with_operator: the element operator L as data.  The row-scaled umbrella

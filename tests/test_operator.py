@@ -68,8 +68,12 @@ def test_explicit_uniform_operator_equals_default(ext):
     sc = scenes.make_scene("kuhn12", 1)
     L = O.element_laplacian(O.face_adjacency(sc.tets))
     ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True)
-    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L)
+    # (same tiling for both: by default explicit-operator plans use smaller tiles, 512 threads / 54 400 B)
+    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L, max_threads=768,
+                          lds_budget_bytes=81920)
     assert ts_d.plan_info()["n_planes"] == 13 and ts_x.plan_info()["n_planes"] == 22
+    auto = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L).plan_info()
+    assert auto["block_threads"] <= 512 and auto["lds_bytes"] <= 54400
     for a, b in zip(TE.plan_tiles(ts_d), TE.plan_tiles(ts_x)):
         assert np.array_equal(a["planes"], b["planes"][:13]) and np.array_equal(a["inc"], b["inc"])
     x = scenes.deform(sc, 0.1)

@@ -986,6 +986,8 @@ hipError_t configure_kernels(int lds_bytes)
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 640, 2, 5, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 640, 2, 5, true>),
                          // rebuild_dminv plans (2 slots per lane)
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, false, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6, false, true>),
@@ -1044,11 +1046,17 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
         if (e.weighted) {
 #define TSAMD_LAUNCH_W(G, S) hipLaunchKernelGGL((tile_energy_kernel<G, 1024, S, 4, true>), grid, block, size_t(lds), stream, k)
-            if (e.spt == 2) {
+#define TSAMD_LAUNCH_W2(G, B, W) hipLaunchKernelGGL((tile_energy_kernel<G, B, 2, W, true>), grid, block, size_t(lds), stream, k)
+            // the nine weight planes cost ten more registers: two workgroups per CU fit up to 640 threads (92 VGPRs, five
+            // waves per SIMD); a 768-thread build at 80 VGPRs spills 13 dwords and measured slower than one workgroup per CU
+            if (e.spt == 2 && e.block_threads <= 640 && e.lds_bytes <= 80 * 1024) {
+                if (e.grad) TSAMD_LAUNCH_W2(true, 640, 5); else TSAMD_LAUNCH_W2(false, 640, 5);
+            } else if (e.spt == 2) {
                 if (e.grad) TSAMD_LAUNCH_W(true, 2); else TSAMD_LAUNCH_W(false, 2);
             } else {
                 if (e.grad) TSAMD_LAUNCH_W(true, 4); else TSAMD_LAUNCH_W(false, 4);
             }
+#undef TSAMD_LAUNCH_W2
 #undef TSAMD_LAUNCH_W
         } else if (e.rebuild) {
 #define TSAMD_LAUNCH_R(G, B, W) hipLaunchKernelGGL((tile_energy_kernel<G, B, 2, W, false, true>), grid, block, size_t(lds), stream, k)

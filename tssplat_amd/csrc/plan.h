@@ -18,8 +18,8 @@ struct PlanOptions {
     // Defaults = the measured optimum on MI355X (profiles/README.md): two 768-thread workgroups per
     // CU, 2 tets per lane, 80 KiB of LDS each -- 24 waves per CU hide the LDS-gather latency that one
     // 1024-thread / 160 KiB workgroup (4 tets per lane) leaves exposed.
-    int lds_budget = 80 * 1024;   // bytes of LDS one workgroup may use
-    int max_threads = 768;        // workgroup size cap (multiple of 64)
+    int lds_budget = 0;           // bytes of LDS one workgroup may use; 0 = 80 KiB (54 400 B with an explicit operator)
+    int max_threads = 0;          // workgroup size cap (multiple of 64); 0 = 768 (512 with an explicit operator)
     int target_owned = 0;         // 0 = auto
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
