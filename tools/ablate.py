@@ -92,7 +92,8 @@ def main():
     _capi.check(lib.tsamd_forward_backward(ts._handle(), x.data_ptr(), None, 1e-4, 2e-4, 2, stream,
                                            e.data_ptr(), g.data_ptr()))
     _capi.check(lib.tsamd_debug_read_clocks(ts._handle(), clk.ctypes.data, clk.size))      # read
-    clk = clk.reshape(-1, 16, 16)[:, :nw, :10].astype(np.float64)
+    raw = clk.reshape(-1, 16, 16)[:, :nw, :].astype(np.float64)
+    clk = raw[:, :, :10]
     names = ["load+stage", "pass1", "pass2", "H write+reload issue", "pass3 (own wave)", "wait others",
              "force write", "vertex gather+stores", "energy reduce"]
     d = np.diff(clk, axis=2)                       # [tile, wave, phase]

@@ -221,6 +221,25 @@ __device__ __forceinline__ Mat9 operator_gather(const unsigned char *lds, const 
     return acc;
 }
 
+// Sum of a double over the 16 lanes of a DPP row, in every lane of the row (same butterfly as wave_sum; a 64-bit value
+// moves as two dwords).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const v2u w = __builtin_bit_cast(v2u, v);
+    const v2u r = {uint32_t(__builtin_amdgcn_update_dpp(0, int(w.x), CTRL, 0xf, 0xf, false)),
+                   uint32_t(__builtin_amdgcn_update_dpp(0, int(w.y), CTRL, 0xf, 0xf, false))};
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double row_sum_f64(double v)
+{
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x124>(v);  // row_ror:4
+    v += dpp_f64<0x128>(v);  // row_ror:8
+    return v;
+}
+
 // Sum over the 64 lanes of a wave, in a fixed order, returned in every lane.  DPP adds inside each row of 16 lanes
 // (no LDS traffic, a few cycles each), then the four row sums through v_readlane.  `__shfl_down` is ds_bpermute on
 // gfx950: twelve dependent LDS round trips for the two energy terms, ~2 000 cycles at the very end of every tile,
@@ -485,8 +504,28 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
             for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
     }
+    // ---- the two energy terms are complete: deterministic block reduction (fixed order; doubles across waves) ----
+    // Done HERE, around a barrier the tile needs anyway, not at the end of the kernel: there the reduction was a serial
+    // tail (wave sums, a barrier, one lane summing the waves) between this workgroup and its successor on the CU --
+    // 450 cycles per tile even after the DPP rework, and the kernel time follows that tail at better than 1 : 1.
+    e_s = wave_sum(e_s);
+    e_b = wave_sum(e_b);
+    const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
+    if (lane == 0) {
+        red[2 * wave] = double(e_s);
+        red[2 * wave + 1] = double(e_b);
+    }
     __syncthreads();  // every read of F is done; overwrite it with H in place
     STAMP(3);  // pass 2 done
+    if (wave == nw - 1) {   // (the last wave has the fewest slots)  lane w fetches wave w's pair, DPP butterfly over <= 16 lanes
+        double s = lane < nw ? red[2 * lane] : 0.0, b = lane < nw ? red[2 * lane + 1] : 0.0;
+        s = row_sum_f64(s);
+        b = row_sum_f64(b);
+        if (lane == 0) {
+            g_partials[2 * size_t(tile)] = s;
+            g_partials[2 * size_t(tile) + 1] = b;
+        }
+    }
 
     if (WITH_GRAD) {
         // vertex incidence lists.  The first K2 vertices of the tile get two lanes each (2v and 2v+1 take the even
@@ -682,25 +721,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         }
     }
 
-    STAMP(8);  // vertex gather + stores done (this wave)
-    // ---- deterministic block reduction of the two energy terms (fixed order; doubles across waves) ----
-    e_s = wave_sum(e_s);
-    e_b = wave_sum(e_b);
-    const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
-    if (lane == 0) {
-        red[2 * wave] = double(e_s);
-        red[2 * wave + 1] = double(e_b);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0, b = 0.0;
-        for (int w = 0; w < nw; ++w) {
-            s += red[2 * w];
-            b += red[2 * w + 1];
-        }
-        g_partials[2 * size_t(tile)] = s;
-        g_partials[2 * size_t(tile) + 1] = b;
-    }
+    STAMP(8);  // vertex gather + stores done (this wave): nothing is left to do, the wave ends here
     STAMP(9);
 }
 
