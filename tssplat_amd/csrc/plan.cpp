@@ -857,7 +857,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 if (opt.conflict_aware) {
                     const int32_t K2 = vertex_two_lane_count(d.n_verts, P.block_threads);
                     const int32_t n_lanes = std::min<int32_t>(2 * K2 + (d.n_verts - K2), std::max(P.block_threads, 2 * K2));
-                    std::vector<uint8_t> placed(4 * size_t(d.n_inc4) + 8, 0);
+                    std::vector<uint8_t> placed(4 * size_t(d.n_inc4) + 8, 0), step_taken(4 * size_t(d.n_inc4) + 8, 0);
                     for (int32_t l0 = 0; l0 < n_lanes; l0 += 32) {
                         const int32_t l1 = std::min<int32_t>(l0 + 32, n_lanes);
                         int32_t steps = 0;
@@ -874,24 +874,84 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                             const int32_t chunks = (cnt[size_t(v)] + 3) / 4;
                             steps = std::max(steps, (chunks - h + stride - 1) / stride);
                         }
+                        // One step = one ds_read of every lane of the group.  Which of its not yet placed entries a
+                        // lane reads in this step is a bipartite matching problem, lanes x bank residues: a MAXIMUM
+                        // matching (augmenting paths) serves the most lanes without a collision; a lane left over takes
+                        // the entry whose residue is least loaded so far.
                         for (int32_t j = 0; j < steps; ++j)
                             for (int32_t q = 0; q < 4; ++q) {
-                                int32_t colrec[32];
-                                for (auto &c : colrec) c = -1;
+                                int32_t nl = 0, lane_v[32], lane_pos[32], lane_len[32];
                                 for (int32_t L = l0; L < l1; ++L) {
                                     int32_t v, h, stride;
                                     lane_of(L, v, h, stride);
                                     const int32_t pos = 4 * (h + stride * j) + q, len = cnt[size_t(v)];
                                     if (pos >= len) continue;
-                                    uint16_t *lst = inc + 4 * size_t(inc_off[v]);
-                                    uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[v]);
-                                    int32_t pick = -1;
-                                    for (int32_t c = 0; c < len && pick < 0; ++c)
-                                        if (!pl_v[c] && colrec[lst[c] & 31u] < 0) pick = c;
-                                    if (pick < 0) pick = pos;  // pos itself is never placed before its own step
-                                    std::swap(lst[pos], lst[pick]);
+                                    lane_v[nl] = v, lane_pos[nl] = pos, lane_len[nl] = len, ++nl;
+                                }
+                                int32_t owner[32], pick[32];   // residue -> lane index, lane index -> list position
+                                for (auto &o : owner) o = -1;
+                                for (int32_t i = 0; i < nl; ++i) pick[i] = -1;
+                                // (the two lanes of a two-lane vertex share one list: an entry taken by the partner in this
+                                // step is skipped through `taken`)
+                                std::vector<uint8_t> &taken = step_taken;
+                                auto entry_free = [&](int32_t i, int32_t c) {
+                                    return !placed[4 * size_t(inc_off[lane_v[i]]) + size_t(c)] && !taken[4 * size_t(inc_off[lane_v[i]]) + size_t(c)];
+                                };
+                                for (int32_t i = 0; i < nl; ++i) {
+                                    // augmenting path from lane i (iterative DFS over at most 32 residues)
+                                    bool seen[32] = {};
+                                    std::function<bool(int32_t)> aug = [&](int32_t li) -> bool {
+                                        const uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[li]]);
+                                        for (int32_t c = 0; c < lane_len[li]; ++c) {
+                                            if (placed[4 * size_t(inc_off[lane_v[li]]) + size_t(c)]) continue;
+                                            const int32_t r = lst[c] & 31;
+                                            if (seen[r]) continue;
+                                            // an entry of a shared list may be held by the partner lane: not available
+                                            if (taken[4 * size_t(inc_off[lane_v[li]]) + size_t(c)] && pick[li] != c) continue;
+                                            seen[r] = true;
+                                            if (owner[r] < 0 || aug(owner[r])) {
+                                                if (pick[li] >= 0) taken[4 * size_t(inc_off[lane_v[li]]) + size_t(pick[li])] = 0;
+                                                owner[r] = li;
+                                                pick[li] = c;
+                                                taken[4 * size_t(inc_off[lane_v[li]]) + size_t(c)] = 1;
+                                                return true;
+                                            }
+                                        }
+                                        return false;
+                                    };
+                                    aug(i);
+                                }
+                                int32_t load[32] = {};
+                                for (int32_t r = 0; r < 32; ++r)
+                                    if (owner[r] >= 0) load[r] = 1;
+                                for (int32_t i = 0; i < nl; ++i) {
+                                    uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
+                                    if (pick[i] < 0) {   // no collision-free entry left for this lane: least loaded residue
+                                        int32_t best = -1;
+                                        for (int32_t c = 0; c < lane_len[i]; ++c)
+                                            if (entry_free(i, c) && (best < 0 || load[lst[c] & 31] < load[lst[best] & 31])) best = c;
+                                        pick[i] = best;
+                                        taken[4 * size_t(inc_off[lane_v[i]]) + size_t(best)] = 1;
+                                        ++load[lst[best] & 31];
+                                    }
+                                }
+                                // commit: move every picked entry to the position its lane reads in this step
+                                for (int32_t i = 0; i < nl; ++i) {
+                                    uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
+                                    uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[lane_v[i]]);
+                                    uint8_t *tk_v = taken.data() + 4 * size_t(inc_off[lane_v[i]]);
+                                    int32_t c = pick[i];
+                                    const int32_t pos = lane_pos[i];
+                                    if (c != pos) {
+                                        // the entry sitting at `pos` may itself be another lane's pick of this step (partner
+                                        // lane of the same list): keep the bookkeeping consistent through the swap
+                                        for (int32_t k = i + 1; k < nl; ++k)
+                                            if (lane_v[k] == lane_v[i] && pick[k] == pos) pick[k] = c;
+                                        std::swap(lst[pos], lst[c]);
+                                        std::swap(tk_v[pos], tk_v[c]);
+                                    }
                                     pl_v[pos] = 1;
-                                    if (colrec[lst[pos] & 31u] < 0) colrec[lst[pos] & 31u] = lst[pos];
+                                    tk_v[pos] = 0;
                                 }
                             }
                     }
