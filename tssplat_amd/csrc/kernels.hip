@@ -508,24 +508,33 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // Done HERE, around a barrier the tile needs anyway, not at the end of the kernel: there the reduction was a serial
     // tail (wave sums, a barrier, one lane summing the waves) between this workgroup and its successor on the CU --
     // 450 cycles per tile even after the DPP rework, and the kernel time follows that tail at better than 1 : 1.
-    e_s = wave_sum(e_s);
-    e_b = wave_sum(e_b);
     const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
-    if (lane == 0) {
-        red[2 * wave] = double(e_s);
-        red[2 * wave + 1] = double(e_b);
-    }
+    auto publish_wave_sums = [&]() {
+        e_s = wave_sum(e_s);
+        e_b = wave_sum(e_b);
+        if (lane == 0) {
+            red[2 * wave] = double(e_s);
+            red[2 * wave + 1] = double(e_b);
+        }
+    };
+    auto sum_waves = [&]() {   // lane w fetches wave w's pair, DPP butterfly over <= 16 lanes; the last wave has the fewest slots
+        if (wave == nw - 1) {
+            double s = lane < nw ? red[2 * lane] : 0.0, b = lane < nw ? red[2 * lane + 1] : 0.0;
+            s = row_sum_f64(s);
+            b = row_sum_f64(b);
+            if (lane == 0) {
+                g_partials[2 * size_t(tile)] = s;
+                g_partials[2 * size_t(tile) + 1] = b;
+            }
+        }
+    };
+    // With a gradient the wave sums go out behind the H stores (their DPP chain overlaps the stores' drain) and are added
+    // up after the next barrier, inside pass 3: tile kernel -0.5 % against doing both around the barrier after pass 2.
+    constexpr bool kSumLate = WITH_GRAD;
+    if (!kSumLate) publish_wave_sums();
     __syncthreads();  // every read of F is done; overwrite it with H in place
     STAMP(3);  // pass 2 done
-    if (wave == nw - 1) {   // (the last wave has the fewest slots)  lane w fetches wave w's pair, DPP butterfly over <= 16 lanes
-        double s = lane < nw ? red[2 * lane] : 0.0, b = lane < nw ? red[2 * lane + 1] : 0.0;
-        s = row_sum_f64(s);
-        b = row_sum_f64(b);
-        if (lane == 0) {
-            g_partials[2 * size_t(tile)] = s;
-            g_partials[2 * size_t(tile) + 1] = b;
-        }
-    }
+    if (!kSumLate) sum_waves();
 
     if (WITH_GRAD) {
         // vertex incidence lists.  The first K2 vertices of the tile get two lanes each (2v and 2v+1 take the even
@@ -554,8 +563,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
             }
         }
+        if (kSumLate) publish_wave_sums();
         __syncthreads();
         STAMP(4);  // H written, reloads issued
+        if (kSumLate) sum_waves();
 
         // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
