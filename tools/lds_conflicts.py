@@ -29,7 +29,7 @@ def group_cycles(keys, addrs):
     return int(np.bincount(pairs[:, 0]).max())
 
 
-def tile_conflicts(T, spt):
+def tile_conflicts(T, spt, nthr=768):
     sp = T["s_pad"]
     nq = sp // spt
     pl = T["planes"]
@@ -62,27 +62,42 @@ def tile_conflicts(T, spt):
                         c = group_cycles(bank, ii)
                         res["g32_base"] += 1
                         res["g32_extra"] += c - 1
-    # per-vertex gather: lanes 2v+h, chunk 2j+h, entry q, component c
+    # per-vertex gather (kernels.hip): the first K2 vertices take two lanes each (even / odd chunks), the others one lane
     inc, off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
     nv = T["n_verts"]
-    for wb in range(0, 2 * nv, 64):
-        us = np.arange(wb, min(wb + 64, 2 * nv))
-        v, h = us >> 1, us & 1
+    K2 = min(nv, nthr - nv) if nv <= nthr else 0
+    n_lanes = 2 * K2 + (nv - K2)
+    lanes_all = np.arange(n_lanes)
+    v_all = np.where(lanes_all < 2 * K2, lanes_all >> 1, K2 + lanes_all - 2 * K2)
+    h_all = np.where(lanes_all < 2 * K2, lanes_all & 1, 0)
+    st_all = np.where(lanes_all < 2 * K2, 2, 1)
+    pad = (T["s_pad"] << 2) | 1
+    res["v_lb"] = 0
+    for wb in range(0, n_lanes, 64):
+        sl = slice(wb, min(wb + 64, n_lanes))
+        v, h, st = v_all[sl], h_all[sl], st_all[sl]
         nch = off[v + 1] - off[v]
-        steps = int(np.max((nch - h + 1) // 2))
+        steps = int(np.max((nch - h + st - 1) // st))
+        per_half = [dict(), dict()]
         for j in range(steps):
-            ch = off[v] + 2 * j + h
+            ch = off[v] + st * j + h
             ok = ch < off[v + 1]
             for q in range(4):
-                e = np.where(ok, inc[np.minimum(4 * ch + q, len(inc) - 1)], (T["s_pad"] << 2) | 1)
-                for comp in range(3):
-                    for half in range(2):
-                        sel = (us - wb) // 32 == half
-                        if not sel.any():
-                            continue
+                e = np.where(ok, inc[np.minimum(4 * ch + q, len(inc) - 1)], pad)
+                for half in range(2):
+                    sel = (np.arange(len(v)) // 32) == half
+                    if not sel.any():
+                        continue
+                    for comp in range(3):
                         c = group_cycles((3 * e[sel] + comp) % 32, e[sel])
                         res["v_base"] += 1
                         res["v_extra"] += c - 1
+                    for x in np.unique(e[sel]):
+                        per_half[half].setdefault(int(x) % 32, set()).add(int(x))
+        # lower bound for this wave: per 32-lane group max(number of read instructions, busiest residue), x 3 components
+        for half in range(2):
+            if per_half[half]:
+                res["v_lb"] += 3 * max(4 * steps, max(len(sx) for sx in per_half[half].values()))
     return res
 
 
@@ -103,7 +118,7 @@ def main():
     for i, T in enumerate(TE.plan_tiles(ts)):
         if i >= args.max_tiles:
             break
-        r = tile_conflicts(T, spt)
+        r = tile_conflicts(T, spt, ts.plan_info()["block_threads"])
         slots += T["n_slots"]
         for k, val in r.items():
             tot[k] = tot.get(k, 0) + val
@@ -111,6 +126,7 @@ def main():
     for k in ("g128", "g32", "v"):
         b, e = tot[k + "_base"] * 64 / slots, tot[k + "_extra"] * 64 / slots
         print(f"  {k:5s} base {b:7.1f}  conflict extra {e:7.1f}  ({e / b:.2f}x)")
+    print(f"  v     lower bound of base + extra for the given lane groups: {tot['v_lb'] * 64 / slots:7.1f}")
 
 
 if __name__ == "__main__":
