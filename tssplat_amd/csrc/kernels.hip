@@ -721,8 +721,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 if (tid & 1) continue;
             }
             GLOBAL_AS float *dst = (v < td.n_excl ? g_grad : g_stage) + size_t(row) * 3;
-            if (DBG(DBG_STORE_LOCAL) || (DBG(DBG_EXCL_LOCAL) && v < td.n_excl) || (DBG(DBG_SHARED_LOCAL) && v >= td.n_excl)) dst = g_stage + size_t(tid) * 3;                          // same store instructions, no HBM writes, no scatter
-            if (DBG(DBG_STORE_TILE)) dst = g_stage + (size_t(tile % 4096) * 1024 + size_t(tid)) * 3;   // coalesced, HBM writes stay
+            if (DBG(DBG_STORE_LOCAL)) dst = g_stage + size_t(tid) * 3;   // same store instructions, no HBM writes, no scatter
             const float sc = v < td.n_excl ? gscale : out_scale;
             if (DBG(DBG_SKIP_OUT)) {
                 if (gx == 1234.5f) dst[0] = gy + gz;
