@@ -303,6 +303,12 @@ def _run_rank(args, stdout_fd: int) -> None:
             log(f"HIP graph capture failed ({exc!r}); using --launch eager")
             graphed = None
 
+    if world > 1 and args.launch in ("auto", "graph"):   # every rank must take the same path through the probes below
+        ok = torch.tensor([1 if graphed is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            graphed = None
+
     pending = []
 
     def step_eager():
