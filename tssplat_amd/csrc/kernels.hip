@@ -29,8 +29,8 @@ namespace {
 
 constexpr int kWave = 64;
 
-// Scheduling fence between the four slots a lane processes in a pass (build with
-// -DTSAMD_NO_SLOT_FENCE to let the compiler interleave them).
+// Scheduling fence between the slots (2 or 4) a lane processes in a pass (build with -DTSAMD_NO_SLOT_FENCE to let
+// the compiler interleave them: measured +0.1 %).
 #ifdef TSAMD_NO_SLOT_FENCE
 #define SLOT_FENCE() ((void)0)
 #else
@@ -242,8 +242,8 @@ __device__ __forceinline__ double row_sum_f64(double v)
 
 // Sum over the 64 lanes of a wave, in a fixed order, returned in every lane.  DPP adds inside each row of 16 lanes
 // (no LDS traffic, a few cycles each), then the four row sums through v_readlane.  `__shfl_down` is ds_bpermute on
-// gfx950: twelve dependent LDS round trips for the two energy terms, ~2 000 cycles at the very end of every tile,
-// where nothing of the workgroup is left to hide them.
+// gfx950: twelve dependent LDS round trips for the two energy terms, ~2 000 cycles per tile (they used to sit at the very
+// end of the kernel, where nothing of the workgroup is left to hide them; the sums now go out behind the H stores).
 __device__ __forceinline__ float wave_sum(float v)
 {
 #define TSAMD_DPP(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, false))
@@ -296,7 +296,9 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 //   [0, 48 SA)        one 48 B record per slot, addressed by lds_index(slot): F (9 floats + pad),
 //                     overwritten by H after pass 2, overwritten by the 4 x 3 vertex forces after pass 3
 //   [48 SA, +16 VP)   xs: float4 per local vertex (staged positions)
-//   then 256 B of reduction scratch.
+//   then 256 B of reduction scratch (the per-wave energy sums, written behind the H stores, added up after the next
+//   barrier by the last wave -- a tile ends with its vertex stores, there is no reduction phase at the end).
+// The passes are separated by six workgroup barriers: staged positions | F | (F reads done) H | H | (H reads done) forces | gather.
 // Lane t's p-th slot lives at index p * nq + t, so a wave's own-slot accesses walk consecutive
 // 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
 // SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
