@@ -897,29 +897,47 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 auto entry_free = [&](int32_t i, int32_t c) {
                                     return !placed[4 * size_t(inc_off[lane_v[i]]) + size_t(c)] && !taken[4 * size_t(inc_off[lane_v[i]]) + size_t(c)];
                                 };
+                                // candidate entries of every lane (not yet placed), gathered once per step
+                                int32_t nc[32];
+                                uint8_t cand_c[32][64], cand_r[32][64];
                                 for (int32_t i = 0; i < nl; ++i) {
-                                    // augmenting path from lane i (iterative DFS over at most 32 residues)
-                                    bool seen[32] = {};
-                                    std::function<bool(int32_t)> aug = [&](int32_t li) -> bool {
-                                        const uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[li]]);
-                                        for (int32_t c = 0; c < lane_len[li]; ++c) {
-                                            if (placed[4 * size_t(inc_off[lane_v[li]]) + size_t(c)]) continue;
-                                            const int32_t r = lst[c] & 31;
+                                    const uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
+                                    const uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[lane_v[i]]);
+                                    int32_t k = 0;
+                                    for (int32_t c = 0; c < lane_len[i] && k < 64; ++c)
+                                        if (!pl_v[c]) cand_c[i][k] = uint8_t(c), cand_r[i][k] = uint8_t(lst[c] & 31), ++k;
+                                    nc[i] = k;
+                                }
+                                struct Matcher {
+                                    int32_t *owner, *pick;
+                                    const int32_t *nc, *lane_v;
+                                    const uint8_t (*cand_c)[64], (*cand_r)[64];
+                                    uint8_t *taken;
+                                    const uint16_t *inc_off;
+                                    bool seen[32];
+                                    bool aug(int32_t li)   // augmenting path from lane li (DFS over at most 32 residues)
+                                    {
+                                        uint8_t *tk = taken + 4 * size_t(inc_off[lane_v[li]]);
+                                        for (int32_t k = 0; k < nc[li]; ++k) {
+                                            const int32_t c = cand_c[li][k], r = cand_r[li][k];
                                             if (seen[r]) continue;
                                             // an entry of a shared list may be held by the partner lane: not available
-                                            if (taken[4 * size_t(inc_off[lane_v[li]]) + size_t(c)] && pick[li] != c) continue;
+                                            if (tk[c] && pick[li] != c) continue;
                                             seen[r] = true;
                                             if (owner[r] < 0 || aug(owner[r])) {
-                                                if (pick[li] >= 0) taken[4 * size_t(inc_off[lane_v[li]]) + size_t(pick[li])] = 0;
+                                                if (pick[li] >= 0) tk[pick[li]] = 0;
                                                 owner[r] = li;
                                                 pick[li] = c;
-                                                taken[4 * size_t(inc_off[lane_v[li]]) + size_t(c)] = 1;
+                                                tk[c] = 1;
                                                 return true;
                                             }
                                         }
                                         return false;
-                                    };
-                                    aug(i);
+                                    }
+                                } M{owner, pick, nc, lane_v, cand_c, cand_r, taken.data(), inc_off, {}};
+                                for (int32_t i = 0; i < nl; ++i) {
+                                    std::memset(M.seen, 0, sizeof(M.seen));
+                                    M.aug(i);
                                 }
                                 int32_t load[32] = {};
                                 for (int32_t r = 0; r < 32; ++r)
