@@ -24,7 +24,7 @@ void colour_group_reads(int nl, const uint32_t cand[][4], uint32_t zs, int from[
     Edge edges[64];
     int ne = 0;
     // virtual columns: (column, copy); each takes at most 4 edges, reads of one record stay together while they fit
-    int vn_count = 0, vn_col[64], vn_deg[64];
+    int vn_count = 0, vn_col[64], vn_deg[64], col_n[16] = {}, col_vn[16][64];
     uint32_t vn_rec[64][4];
     for (int li = 0; li < nl; ++li)
         for (int c = 0; c < 4; ++c) {
@@ -32,16 +32,20 @@ void colour_group_reads(int nl, const uint32_t cand[][4], uint32_t zs, int from[
             if (rec == zs) continue;
             const int col = int(rec & 15u);
             int pick = -1;
-            for (int v = 0; v < vn_count && pick < 0; ++v)   // a copy of this column that already holds this record
-                if (vn_col[v] == col && vn_deg[v] < 4)
+            // (the copies of one column, in creation order: the same choices as a scan over all virtual nodes)
+            for (int k = 0; k < col_n[col] && pick < 0; ++k) {   // a copy of this column that already holds this record
+                const int v = col_vn[col][k];
+                if (vn_deg[v] < 4)
                     for (int i = 0; i < vn_deg[v]; ++i)
                         if (vn_rec[v][i] == rec) pick = v;
-            for (int v = 0; v < vn_count && pick < 0; ++v)
-                if (vn_col[v] == col && vn_deg[v] < 4) pick = v;
+            }
+            for (int k = 0; k < col_n[col] && pick < 0; ++k)
+                if (vn_deg[col_vn[col][k]] < 4) pick = col_vn[col][k];
             if (pick < 0) {
                 pick = vn_count++;
                 vn_col[pick] = col;
                 vn_deg[pick] = 0;
+                col_vn[col][col_n[col]++] = pick;
             }
             vn_rec[pick][vn_deg[pick]++] = rec;
             edges[ne++] = Edge{li, c, pick, -1};
