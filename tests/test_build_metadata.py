@@ -1,0 +1,30 @@
+"""Kernel descriptors of the gfx950 code object the library was built with (no GPU needed).
+
+The tile kernels address LDS by absolute byte address (kernels.hip: lds_at): correct only while they have no static
+LDS object, which the library re-checks at run time (configure_kernels) and this test checks at build time.  Their
+occupancy (two 768-thread workgroups per CU) needs <= 80 VGPRs without spills."""
+import os
+import sys
+
+import pytest
+
+from tssplat_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM tools")
+def test_tile_kernels_have_no_static_lds_and_do_not_spill():
+    import kernel_metadata
+    _capi.load()
+    meta = kernel_metadata.kernel_metadata(_capi.lib_path())
+    tiles = {k: v for k, v in meta.items() if "tile_energy_kernel" in k}
+    assert len(tiles) == 6, sorted(tiles)          # built-in, explicit operator, rebuild_dminv -- each with / without gradient
+    for name, rec in tiles.items():
+        assert rec["group_segment_fixed_size"] == 0, (name, rec)      # dynamic LDS array at LDS address 0
+        assert rec["vgpr_spill_count"] == 0 and rec["private_segment_fixed_size"] == 0, (name, rec)
+    default = [v for k, v in tiles.items() if "ILb1ELi768ELi6ELb0ELb0E" in k]
+    assert len(default) == 1 and default[0]["vgpr_count"] <= 80, default      # 6 waves per SIMD: two workgroups per CU
+    for name, rec in meta.items():
+        assert rec["vgpr_spill_count"] == 0, (name, rec)

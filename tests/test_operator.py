@@ -49,7 +49,7 @@ def _replay(ext, sc, L, kw, cases=((0.02, 2, 1.0), (0.3, 4, 0.5))):
 @pytest.mark.parametrize("kind,S,kw", [
     ("kuhn8", 2, {}),
     ("kuhn12", 1, {}),                                              # bisected: halo slots carry column weights
-    ("kuhn12", 1, dict(slots_per_thread=4, max_threads=512)),
+    ("kuhn12", 1, dict(max_threads=640, lds_budget_bytes=100000)),
     ("kuhn12", 1, dict(debug_shuffle=2)),                           # no conflict-aware re-ordering of the neighbours
     ("delaunay700", 2, dict(lds_budget_bytes=40000)),
 ])
@@ -67,10 +67,10 @@ def test_explicit_uniform_operator_equals_default(ext):
     planes of the two plans are identical."""
     sc = scenes.make_scene("kuhn12", 1)
     L = O.element_laplacian(O.face_adjacency(sc.tets))
-    ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True)
     # (same tiling for both: by default explicit-operator plans use smaller tiles, 512 threads / 54 400 B)
-    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L, max_threads=768,
-                          lds_budget_bytes=81920)
+    ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, max_threads=640, lds_budget_bytes=68000)
+    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L, max_threads=640,
+                          lds_budget_bytes=68000)
     assert ts_d.plan_info()["n_planes"] == 13 and ts_x.plan_info()["n_planes"] == 22
     auto = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L).plan_info()
     assert auto["block_threads"] <= 512 and auto["lds_bytes"] <= 54400
@@ -120,3 +120,30 @@ def test_operator_validation(ext):
         ext.TetSpheres(v, t, host_only=True, operator=sp.identity(m + 1, format="csr"))
     with pytest.raises(TypeError):
         ext.TetSpheres("x.veg", host_only=True, operator=csr)
+
+
+def test_operator_csr_is_validated(ext):
+    """a CSR that starts anywhere but 0, non-finite weights and operator + rebuild_dminv are errors, not
+    silently accepted inputs."""
+    sc = scenes.make_scene("kuhn3", 1)
+    v, t = sc.rest.reshape(-1), sc.tets.reshape(-1)
+    csr = O.element_laplacian(O.face_adjacency(sc.tets)).tocsr()
+    rp, ci, va = csr.indptr.astype(np.int64), csr.indices.astype(np.int32), csr.data.astype(np.float64)
+    bad_rp = rp.copy()
+    bad_rp[0] = -3
+    with pytest.raises(RuntimeError, match=r"rowptr\[0\] must be 0"):
+        ext.TetSpheres(v, t, host_only=True, operator=(bad_rp, ci, va))
+    for poison in (np.nan, np.inf):
+        bad_va = va.copy()
+        bad_va[5] = poison
+        with pytest.raises(RuntimeError, match="non-finite value"):
+            ext.TetSpheres(v, t, host_only=True, operator=(rp, ci, bad_va))
+    with pytest.raises(RuntimeError, match="not combined with rebuild_dminv"):
+        ext.TetSpheres(v, t, host_only=True, operator=csr, rebuild_dminv=True)
+    # explicit-operator kernels are compiled for at most 640 threads; the built-in ones for 768; 4 slots per lane are gone
+    with pytest.raises(RuntimeError, match="max_threads exceeds"):
+        ext.TetSpheres(v, t, host_only=True, operator=csr, max_threads=768)
+    with pytest.raises(RuntimeError, match="max_threads exceeds"):
+        ext.TetSpheres(v, t, host_only=True, max_threads=1024)
+    with pytest.raises(RuntimeError, match="slots_per_thread must be 0 or 2"):
+        ext.TetSpheres(v, t, host_only=True, slots_per_thread=4)

@@ -35,7 +35,7 @@ def _check(ext, sc, kw, cases=((0.3, 4, 0.5),)):
 
 @pytest.mark.parametrize("kind,S,kw", [
     ("kuhn8", 3, {}),                                  # default: two workgroups per CU, 2 tets per lane
-    ("kuhn8", 3, dict(slots_per_thread=4, max_threads=1024, lds_budget_bytes=163840)),   # one tile per sphere, no halo
+    ("kuhn8", 3, dict(max_threads=768, lds_budget_bytes=163840)),   # one workgroup per CU
     ("kuhn8", 2, dict(lds_budget_bytes=40000)),        # forced multi-tile
     ("kuhn3", 40, {}),                                 # many tiny spheres packed into shared tiles
     ("kuhn12", 1, {}),                                 # ~10k tets: bisected
@@ -59,9 +59,9 @@ def test_plan_replays_to_oracle(ext, kind, S, kw):
     # sliver removal can split a Delaunay ball into several face-connected pieces
     assert info["n_components"] == S or (kind.startswith("delaunay") and info["n_components"] >= S)
     assert info["total_slots"] >= sc.n_tets
-    assert info["block_threads"] % 64 == 0 and 64 <= info["block_threads"] <= 1024
+    assert info["block_threads"] % 64 == 0 and 64 <= info["block_threads"] <= 768
     assert info["lds_bytes"] <= (kw.get("lds_budget_bytes") or 81920)
-    assert info["slots_per_thread"] == kw.get("slots_per_thread", 2)
+    assert info["slots_per_thread"] == 2
     assert info["slots_per_thread"] * info["block_threads"] >= info["max_slots"]
     assert info["n_planes"] == (4 if kw.get("rebuild_dminv") else 13)
 
@@ -199,16 +199,16 @@ from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E
 @given(kind=st.sampled_from(["kuhn2", "kuhn4", "kuhn6", "delaunay150", "delaunay500", "cone"]),
        spheres=st.integers(1, 3),
        lds=st.sampled_from([0, 12000, 24000, 40960, 65536, 81920, 120000, 163840]),
-       threads=st.sampled_from([0, 64, 128, 256, 512, 768, 1024]),
-       spt=st.sampled_from([2, 4]),
+       threads=st.sampled_from([0, 64, 128, 256, 512, 640, 768]),
+       rebuild=st.booleans(),
        balance=st.booleans(),
        target=st.sampled_from([0, 50, 300, 1000]),
        debug=st.integers(0, 3),
        seed=st.integers(0, 3))
-def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, spt, balance, target, debug, seed):
+def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, rebuild, balance, target, debug, seed):
     from tssplat_amd import tet_spheres_ext as ext
     sc = scenes.make_scene(kind, spheres, seed=seed)
-    kw = dict(lds_budget_bytes=lds, max_threads=threads, slots_per_thread=spt, balance_slots=balance,
+    kw = dict(lds_budget_bytes=lds, max_threads=threads, rebuild_dminv=rebuild, balance_slots=balance,
               target_owned=target, debug_shuffle=debug)
     try:
         ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, **kw)
@@ -218,7 +218,7 @@ def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, spt, balance
     info = ts.plan_info()
     assert info["lds_bytes"] <= (lds or 81920) and info["block_threads"] <= (threads or 768)
     assert info["slots_per_thread"] * info["block_threads"] >= info["max_slots"]
-    cache = O.prepare(sc.rest, sc.tets)
+    cache = O.prepare(sc.rest, sc.tets, round_fp32=not rebuild)   # (rebuild plans replay the unrounded operator)
     x = scenes.deform(sc, 0.2, seed=seed + 7)
     E, Es, Eb, g = O.energy_and_grad(x, cache, 3e-5, 2e-4, 4, grad_output=0.7)
     E2, Es2, Eb2, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 4, grad_output=0.7)

@@ -126,7 +126,11 @@ int to_device(tsamd_handle *h, int device)
     TSAMD_HIP(hipMemset(h->d_terms, 0, 2 * sizeof(double)));
     {
         const int32_t lds_p = int32_t(tsamd::tile_lds_bytes((P.max_slots + 3) & ~3, P.max_verts, P.n_planes == tsamd::kPlanesRebuild));
-        TSAMD_HIP(tsamd::configure_kernels(std::max(P.lds_bytes, lds_p <= 160 * 1024 ? lds_p : P.lds_bytes)));
+        const hipError_t ce = tsamd::configure_kernels(std::max(P.lds_bytes, lds_p <= 160 * 1024 ? lds_p : P.lds_bytes));
+        if (ce == hipErrorInvalidDeviceFunction)
+            return fail(TSAMD_ERR_HIP, "a tile kernel of this build has a static LDS object: its dynamic LDS array no longer starts at LDS "
+                                       "address 0, which the kernels' absolute LDS addressing relies on (kernels.hip: lds_at)");
+        TSAMD_HIP(ce);
     }
     return TSAMD_OK;
 }
@@ -153,10 +157,9 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.num_threads = opt.num_threads;
     po.shuffle = opt.debug_shuffle & 1;
     po.conflict_aware = (opt.debug_shuffle & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware ordering off
-    if (opt.slots_per_thread == 2 || opt.slots_per_thread == 4) po.slots_per_thread = opt.slots_per_thread;
+    if (opt.slots_per_thread != 0 && opt.slots_per_thread != tsamd::kSlotsPerLane)
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread must be 0 or 2 (the 4-slot kernels were removed: they spilled and measured 25-45 % slower)");
     po.rebuild_dminv = opt.rebuild_dminv ? 1 : 0;
-    if (po.rebuild_dminv && po.slots_per_thread != 2)
-        return fail(TSAMD_ERR_INVALID_ARGUMENT, "rebuild_dminv needs slots_per_thread = 2");
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;
@@ -210,7 +213,6 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.n_finish = int64_t(h->plan.fin_vid.size());
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
-    a.spt = h->plan.spt;
     a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
     a.rebuild = h->plan.n_planes == tsamd::kPlanesRebuild;
     a.dbg = h->dbg;

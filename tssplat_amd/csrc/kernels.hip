@@ -135,8 +135,9 @@ struct Mat9 {
 };
 
 // LDS accesses by absolute byte address.  The kernels' only LDS object is the dynamic array, which starts at LDS
-// address 0 (asserted on the host: the kernels declare no static __shared__ object, and a device-side check in
-// the prologue costs 26 VGPRs, see profiles/r02_experiments.md); addressing it as `smem + offset` makes the compiler add the array's link-time
+// address 0 as long as a kernel has no static LDS object: configure_kernels() checks exactly that for every tile
+// kernel instantiation (hipFuncGetAttributes: sharedSizeBytes == 0) and refuses to run otherwise (a device-side check
+// in the prologue costs 26 VGPRs, see profiles/r02_experiments.md); addressing it as `smem + offset` makes the compiler add the array's link-time
 // address -- a literal 0 -- to every computed offset: one wasted VALU instruction per access in a kernel that is
 // bound by instruction issue.
 #define LDS_AS __attribute__((address_space(3)))
@@ -301,32 +302,29 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // The passes are separated by six workgroup barriers: staged positions | F | (F reads done) H | H | (H reads done) forces | gather.
 // Lane t's p-th slot lives at index p * nq + t, so a wave's own-slot accesses walk consecutive
 // 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
-// SPT = slots per lane (the plan is laid out for it), BLOCK / WPE = launch bounds (threads, waves per
-// SIMD): <1024, 4> gives 128 VGPRs and one workgroup per CU, <768, 6> 80 VGPRs and two.
+// Two slots per lane (kSlotsPerLane; the plan is laid out for it); launch bounds <768 threads, 6 waves per SIMD> give the
+// 80-VGPR budget at which two workgroups share a CU.  (Round 2 also carried 4-slots-per-lane and 1024-thread
+// builds: they spilled or ran one workgroup per CU, measured 25-45 % slower, and were removed in round 3.)
 // Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
 // prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
 // within noise: DESIGN.md section 4.)
-template <bool WITH_GRAD, int SPT, bool WEIGHTED, bool REBUILD>
+template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD>
 __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
 {
+    constexpr int SPT = kSlotsPerLane;
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
     // out-of-line copy would turn into a flat_* instruction
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
     typedef float VF __attribute__((ext_vector_type(SPT)));
-#ifdef TSAMD_FORCE_RELOAD
-    constexpr bool kReload = true;
-#else
-    constexpr bool kReload = SPT > 2;
-#endif
-    static_assert(!(REBUILD && (WEIGHTED || kReload)), "rebuild_dminv is built for 2 slots per lane and the built-in operator");
+    static_assert(!(REBUILD && WEIGHTED), "rebuild_dminv is built for the built-in operator");
     // 2 slots per lane: a slot's own F stays in registers from pass 1 to pass 2 instead of being read back from LDS
     // (-8 LDS cycles per 64 slots, tile kernel -0.9 %).  Keeping the own H for pass 3 as well was measured: both slots
     // spill 3 dwords, one slot alone gains 0.5 % and nothing on top of the F variant (profiles/r02_experiments.md).
 #ifdef TSAMD_KEEP_OWN
     constexpr int kKeepF = TSAMD_KEEP_OWN & 1 ? SPT : 0, kKeepH = TSAMD_KEEP_OWN & 2 ? SPT : (TSAMD_KEEP_OWN & 4 ? 1 : 0);
 #else
-    constexpr int kKeepF = SPT == 2 ? SPT : 0, kKeepH = 0;
+    constexpr int kKeepF = SPT, kKeepH = 0;
 #endif
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -405,9 +403,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 
     // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
     // dE/dF = c1 (Q + (c2 / c1) pen' cof F), so pass 3 works with s_pen = c2 / c1 and the per-vertex sums are scaled
-    // by c1 (and by grad_output) when they are written.  c1 == 0 drops Q instead.
-    const bool use_c1 = k_c1 != 0.f;
-    const float s_pen = use_c1 ? k_c2 / k_c1 : k_c2, out_scale = use_c1 ? k_c1 : 1.f;
+    // by c1 (and by grad_output) when they are written.
+    // Only while c2 / c1 is a well-behaved fp32 number: a tiny c1 would make the ratio overflow (inf * 0 = NaN on every
+    // owned, non-inverted tet) or swamp Q's bits.  Outside that range -- and for c1 == 0, which drops Q -- pass 3 applies
+    // c1 to Q and c2 to the penalty separately (q_scale) and the vertex sums are written unscaled.
+    const float ratio = k_c2 / k_c1;
+    const bool factored = k_c1 != 0.f && __builtin_fabsf(ratio) <= 0x1p+40f;   // (false for inf and NaN as well)
+    const float s_pen = factored ? ratio : k_c2, out_scale = factored ? k_c1 : 1.f, q_scale = factored ? 1.f : k_c1;
     // byte address of each own record's ninth entry (see load_slot), once per slot instead of once per access
     uint32_t t_own[SPT];
 #pragma unroll
@@ -549,15 +551,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         int pc0 = 0, pc1 = 0;
         v2u pre[kPre];
         if (active) {
-            // Dm^-1 is needed again by pass 3.  With 4 slots per lane, pinning its 36 VGPRs (+8 of vertex
-            // offsets) across pass 2 spills, so those builds re-issue the 11 plane loads here (L2 hit rate
-            // 44 %: the measured 1.5x HBM over-fetch).  With 2 slots per lane it stays in registers.
-            if (kReload) {
-                q_lv01 = plane_u(0);
-                q_lv23 = plane_u(1);
-#pragma unroll
-                for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
-            }
+            // (Dm^-1, needed again by pass 3, stays in registers)
 #pragma unroll
             for (int p = 0; p < SPT; ++p) store_slot(smem, t_own[p], H[p]);   // (zeros on halo and padding slots)
             if (WEIGHTED) {   // pass 3 applies L^T: the column weights L[n_k, e]
@@ -611,14 +605,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 }
 #endif
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
-                if (!use_c1) {   // smoothness switched off: only the penalty term is left
+                if (!factored) {   // rare: c1 == 0 (only the penalty term is left) or c2 / c1 out of range
 #pragma unroll
-                    for (int c = 0; c < 9; ++c) P[c] = 0.f;
+                    for (int c = 0; c < 9; ++c) P[c] *= q_scale;
                 }
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    if (!kReload) {  // rare path: fetch the vertex offsets again instead of pinning them (the address is
-                                     // rebuilt from an opaque copy of the lane id, or it would be kept in two VGPRs
-                                     // from the stream phase on)
+                    {   // rare path: fetch the vertex offsets again instead of pinning them (the address is rebuilt from an
+                        // opaque copy of the lane id, or it would be kept in two VGPRs from the stream phase on)
                         int lt2 = lt;
                         asm volatile("" : "+v"(lt2));
                         q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
@@ -646,7 +639,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
         // (computed here, not earlier: nothing of it needs to stay live across pass 3)
-        const int K2 = td.n_verts <= nthr ? (td.n_verts < nthr - td.n_verts ? td.n_verts : nthr - td.n_verts) : 0;  // = plan.h: vertex_two_lane_count
+        const int K2 = vertex_two_lane_count(td.n_verts, nthr);
         const bool two_lane = tid < 2 * K2;
         const int my_v = two_lane ? tid >> 1 : K2 + (tid - 2 * K2), my_stride = two_lane ? 2 : 1;
         const bool has_vertex = my_v < td.n_verts;
@@ -745,7 +738,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 
 
 
-template <bool WITH_GRAD, int BLOCK, int SPT, int WPE, bool WEIGHTED = false, bool REBUILD = false>
+template <bool WITH_GRAD, int BLOCK, int WPE, bool WEIGHTED = false, bool REBUILD = false>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -757,11 +750,12 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
     const int tile = xcd * a.tiles_per_xcd + jb;
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
-    // (lds_at() assumes the dynamic LDS array starts at LDS address 0: true for a kernel without static LDS objects.  A
-    // run-time check here costs more than it looks: a trap in the prologue turns the descriptor loads into vector loads
-    // and their 12 dwords, and every address derived from them, into VGPRs -- measured +26 VGPRs.)
+    // (lds_at() assumes the dynamic LDS array starts at LDS address 0: true for a kernel without static LDS objects,
+    // which configure_kernels() verifies on the host.  A run-time check here costs more than it looks: a trap in the
+    // prologue turns the descriptor loads into vector loads and their 12 dwords, and every address derived from them,
+    // into VGPRs -- measured +26 VGPRs.)
     const TileDesc td0 = a.tiles[tile];
-    tile_body<WITH_GRAD, SPT, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
+    tile_body<WITH_GRAD, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
 }
 
 struct FinishArgs {
@@ -1041,26 +1035,23 @@ hipError_t configure_kernels(int lds_bytes)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (lds_bytes <= configured[dev]) return hipSuccess;
-    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6>),
-                         // explicit-operator builds (one more register-hungry stream: 128-VGPR launch bounds)
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 4, 4, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 4, 4, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 640, 2, 5, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 640, 2, 5, true>),
-                         // rebuild_dminv plans (2 slots per lane)
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 768, 2, 6, false, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 768, 2, 6, false, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, 1024, 2, 4, false, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, 1024, 2, 4, false, true>)};
+    // every tile kernel a plan can reach: the built-in operator, an explicit operator, rebuild_dminv -- each with and
+    // without the gradient
+    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreadsWeighted, kWavesWeighted, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreadsWeighted, kWavesWeighted, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6, false, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6, false, true>)};
     for (const void *fn : fns) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        // lds_at() addresses the dynamic LDS array by absolute byte address: that is only right while the array starts
+        // at LDS address 0, i.e. while the kernel has no static LDS object in front of it (a static __shared__ variable,
+        // an LDS-using helper that was not inlined, a compiler-generated module-LDS block)
+        hipFuncAttributes attr;
+        hipError_t e = hipFuncGetAttributes(&attr, fn);
+        if (e != hipSuccess) return e;
+        if (attr.sharedSizeBytes != 0) return hipErrorInvalidDeviceFunction;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return e;
     }
     configured[dev] = lds_bytes;
@@ -1100,44 +1091,23 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.dbg = e.dbg;
         k.clk = e.clk;
         const dim3 block(unsigned(e.block_threads));
-        // 2 slots per lane and two workgroups per CU (<= 80 KiB LDS, <= 768 threads): the 80-VGPR build
-        const bool two_per_cu = e.spt == 2 && e.block_threads <= 768 && e.lds_bytes <= 80 * 1024;
-#define TSAMD_LAUNCH(G, B, S, W) \
-    hipLaunchKernelGGL((tile_energy_kernel<G, B, S, W>), grid, block, size_t(lds), stream, k)
 #ifdef TSAMD_ABLATION
         const size_t lds = ablation_lds_request(size_t(e.lds_bytes));
 #else
         const size_t lds = size_t(e.lds_bytes);
 #endif
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
+        if (e.block_threads > (e.weighted ? kTileThreadsWeighted : kTileThreads)) return hipErrorInvalidConfiguration;
+#define TSAMD_LAUNCH(...) hipLaunchKernelGGL((tile_energy_kernel<__VA_ARGS__>), grid, block, lds, stream, k)
         if (e.weighted) {
-#define TSAMD_LAUNCH_W(G, S) hipLaunchKernelGGL((tile_energy_kernel<G, 1024, S, 4, true>), grid, block, size_t(lds), stream, k)
-#define TSAMD_LAUNCH_W2(G, B, W) hipLaunchKernelGGL((tile_energy_kernel<G, B, 2, W, true>), grid, block, size_t(lds), stream, k)
-            // the nine weight planes cost ten more registers: two workgroups per CU fit up to 640 threads (92 VGPRs, five
-            // waves per SIMD); a 768-thread build at 80 VGPRs spills 13 dwords and measured slower than one workgroup per CU
-            if (e.spt == 2 && e.block_threads <= 640 && e.lds_bytes <= 80 * 1024) {
-                if (e.grad) TSAMD_LAUNCH_W2(true, 640, 5); else TSAMD_LAUNCH_W2(false, 640, 5);
-            } else if (e.spt == 2) {
-                if (e.grad) TSAMD_LAUNCH_W(true, 2); else TSAMD_LAUNCH_W(false, 2);
-            } else {
-                if (e.grad) TSAMD_LAUNCH_W(true, 4); else TSAMD_LAUNCH_W(false, 4);
-            }
-#undef TSAMD_LAUNCH_W2
-#undef TSAMD_LAUNCH_W
+            if (e.grad) TSAMD_LAUNCH(true, kTileThreadsWeighted, kWavesWeighted, true);
+            else TSAMD_LAUNCH(false, kTileThreadsWeighted, kWavesWeighted, true);
         } else if (e.rebuild) {
-#define TSAMD_LAUNCH_R(G, B, W) hipLaunchKernelGGL((tile_energy_kernel<G, B, 2, W, false, true>), grid, block, size_t(lds), stream, k)
-            if (two_per_cu) {
-                if (e.grad) TSAMD_LAUNCH_R(true, 768, 6); else TSAMD_LAUNCH_R(false, 768, 6);
-            } else {
-                if (e.grad) TSAMD_LAUNCH_R(true, 1024, 4); else TSAMD_LAUNCH_R(false, 1024, 4);
-            }
-#undef TSAMD_LAUNCH_R
-        } else if (e.spt == 2 && two_per_cu) {
-            if (e.grad) TSAMD_LAUNCH(true, 768, 2, 6); else TSAMD_LAUNCH(false, 768, 2, 6);
-        } else if (e.spt == 2) {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 2, 4); else TSAMD_LAUNCH(false, 1024, 2, 4);
+            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6, false, true);
+            else TSAMD_LAUNCH(false, kTileThreads, 6, false, true);
         } else {
-            if (e.grad) TSAMD_LAUNCH(true, 1024, 4, 4); else TSAMD_LAUNCH(false, 1024, 4, 4);
+            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6);
+            else TSAMD_LAUNCH(false, kTileThreads, 6);
         }
 #undef TSAMD_LAUNCH
         hipError_t err = hipGetLastError();

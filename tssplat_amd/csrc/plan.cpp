@@ -318,13 +318,18 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
     nthreads = std::max(1, std::min(nthreads, 64));
-    const int spt = opt.slots_per_thread == 4 ? 4 : 2;
+    constexpr int spt = kSlotsPerLane;
     // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU.  Plans with an explicit operator carry nine more
     // planes and their kernel needs 92 VGPRs (five waves per SIMD): 512-thread tiles of <= 54 400 B measured fastest
     // (64 x kuhn19: 0.096 ms against 0.111 ms for 768-thread tiles at one workgroup per CU, 0.119 ms for 640 x 2).
-    const bool small_tiles = op != nullptr && spt == 2;
-    int max_threads = opt.max_threads > 0 ? opt.max_threads : (small_tiles ? 512 : 768);
-    max_threads = std::max(64, std::min(1024, (max_threads / 64) * 64));
+    const bool small_tiles = op != nullptr;
+    const int thread_cap = op != nullptr ? kTileThreadsWeighted : kTileThreads;
+    if (opt.max_threads > thread_cap) {
+        err = "max_threads exceeds what the tile kernels are compiled for (" + std::to_string(thread_cap) + ")";
+        return ERR_INVALID;
+    }
+    int max_threads = opt.max_threads > 0 ? opt.max_threads : (small_tiles ? 512 : kTileThreads);
+    max_threads = std::max(64, (max_threads / 64) * 64);
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : (small_tiles ? 54400 : 80 * 1024);
     lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 2728);  // record tokens (12 idx + rot) are 15-bit fields
@@ -348,6 +353,14 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             err = "element operator: null CSR array";
             return ERR_INVALID;
         }
+        if (op->rowptr[0] != 0 || op->rowptr[m] < 0) {
+            err = "element operator: rowptr[0] must be 0 and rowptr[m] non-negative";
+            return ERR_INVALID;
+        }
+        if (opt.rebuild_dminv) {
+            err = "element operator: not combined with rebuild_dminv (the explicit-operator kernels stream Dm^-1)";
+            return ERR_INVALID;
+        }
         P.n_planes = kPlanesWeighted;
         P.op_diag.assign(size_t(m), 0.f);
         P.op_w.assign(size_t(4 * m), 0.f);
@@ -360,6 +373,10 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             for (int64_t q = op->rowptr[e]; q < op->rowptr[e + 1]; ++q) {
                 const int64_t j = op->col[q];
                 const double v = op->val[q];
+                if (!std::isfinite(v)) {
+                    err = "element operator: non-finite value in row " + std::to_string(e);
+                    return ERR_INVALID;
+                }
                 if (j == e) {
                     dg[size_t(e)] += v;
                     continue;
@@ -899,19 +916,21 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 };
                                 // candidate entries of every lane (not yet placed), gathered once per step
                                 int32_t nc[32];
-                                uint8_t cand_c[32][64], cand_r[32][64];
+                                uint16_t cand_c[32][64];   // list positions: a hub vertex has more than 255 incident slots
+                                uint8_t cand_r[32][64];
                                 for (int32_t i = 0; i < nl; ++i) {
                                     const uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
                                     const uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[lane_v[i]]);
                                     int32_t k = 0;
                                     for (int32_t c = 0; c < lane_len[i] && k < 64; ++c)
-                                        if (!pl_v[c]) cand_c[i][k] = uint8_t(c), cand_r[i][k] = uint8_t(lst[c] & 31), ++k;
+                                        if (!pl_v[c]) cand_c[i][k] = uint16_t(c), cand_r[i][k] = uint8_t(lst[c] & 31), ++k;
                                     nc[i] = k;
                                 }
                                 struct Matcher {
                                     int32_t *owner, *pick;
                                     const int32_t *nc, *lane_v;
-                                    const uint8_t (*cand_c)[64], (*cand_r)[64];
+                                    const uint16_t (*cand_c)[64];
+                                    const uint8_t (*cand_r)[64];
                                     uint8_t *taken;
                                     const uint16_t *inc_off;
                                     bool seen[32];

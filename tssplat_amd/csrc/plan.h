@@ -12,6 +12,13 @@
 #include <string>
 #include <vector>
 
+// (the one function the kernels share with the planner is marked for both sides when hipcc compiles this header)
+#ifdef __HIPCC__
+#define TSAMD_HOST_DEVICE __host__ __device__
+#else
+#define TSAMD_HOST_DEVICE
+#endif
+
 namespace tsamd {
 
 struct PlanOptions {
@@ -19,12 +26,11 @@ struct PlanOptions {
     // CU, 2 tets per lane, 80 KiB of LDS each -- 24 waves per CU hide the LDS-gather latency that one
     // 1024-thread / 160 KiB workgroup (4 tets per lane) leaves exposed.
     int lds_budget = 0;           // bytes of LDS one workgroup may use; 0 = 80 KiB (54 400 B with an explicit operator)
-    int max_threads = 0;          // workgroup size cap (multiple of 64); 0 = 768 (512 with an explicit operator)
+    int max_threads = 0;          // workgroup size cap (multiple of 64, <= kTileThreads / kTileThreadsWeighted); 0 = 768 (512 with an explicit operator)
     int target_owned = 0;         // 0 = auto
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
     int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
-    int slots_per_thread = 2;     // 2 or 4 consecutive slots streamed by one lane (8 or 16 B loads)
     int conflict_aware = 1;       // order neighbour / incidence entries to dodge LDS bank conflicts
     int rebuild_dminv = 0;        // 1 = do not stream Dm^-1 (36 of the 52 bytes per slot): keep each tile's REST positions
                                   // (16 B per tile vertex) and invert Dm in registers, in fp32 (see kPlanesRebuild)
@@ -51,6 +57,13 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI
 //                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
 //   n_verts + 1 x u16         : first chunk of every local vertex
 constexpr int kPlanes = 13;
+// Lane layout the kernels are compiled for: two consecutive slots per lane (one 8-byte load per plane), workgroups of
+// at most 768 threads (80-VGPR build: two workgroups per CU when a tile's LDS is <= 80 KiB); explicit-operator plans
+// use at most 640 (92 VGPRs, five waves per SIMD).
+constexpr int kSlotsPerLane = 2;
+constexpr int kTileThreads = 768;
+constexpr int kTileThreadsWeighted = 640;
+constexpr int kWavesWeighted = 5;
 // Plans built with an explicit element operator (build_plan's `op`) carry 9 more fp32 planes per slot:
 //   [13]      L[e, e]
 //   [14..17]  L[e, n_k]   row weights, in the slot's (possibly re-ordered) neighbour order -- pass 2, H = L F
@@ -88,7 +101,7 @@ constexpr int kMaxTileVerts = 2047;
 // chunks of the list -- and the other n_verts - K2 one lane each, so that every vertex is served in ONE round and
 // no lane walks a second vertex (round 1: two lanes for everybody, the first 2 n_verts - nthr lanes then took a
 // second vertex, cold, while eleven of the twelve waves waited for them).
-inline int32_t vertex_two_lane_count(int32_t n_verts, int32_t nthr)
+TSAMD_HOST_DEVICE inline int32_t vertex_two_lane_count(int32_t n_verts, int32_t nthr)
 {
     return n_verts <= nthr ? (n_verts < nthr - n_verts ? n_verts : nthr - n_verts) : 0;
 }
@@ -129,7 +142,7 @@ struct Plan {
     std::vector<int32_t> fin_vid, fin_off, fin_idx;
     int64_t n_stage = 0;             // rows in the staging buffer
     int64_t total_slots = 0, total_tile_verts = 0;
-    int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0, spt = 4;
+    int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0, spt = kSlotsPerLane;
     int32_t n_planes = kPlanes;      // kPlanes, or kPlanesWeighted when an explicit operator was given
     std::vector<float> op_diag;      // explicit operator only: L[e,e] per tet
     std::vector<float> op_w;         // explicit operator only: L[e, nbr[4e+k]] per tet face (0 on boundary faces)

@@ -67,10 +67,7 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
     def forward(self, x, it, c1, c2):
         order = 4 if it > self.FLAGS.increase_order_iter else 2      # smooth_barrier.py:61-63
         if not torch.is_grad_enabled():
-            # logging / validation under torch.no_grad(): energy only -- no fused gradient pass, nothing left in the cache
-            fuse, self.tet_sp.fuse_forward_backward = self.tet_sp.fuse_forward_backward, False
-            try:
-                return tet_spheres_ext.forward(x, self.tet_sp, c1, c2, order)
-            finally:
-                self.tet_sp.fuse_forward_backward = fuse
+            # logging / validation under torch.no_grad(): energy only -- no fused gradient pass, and a gradient kept for a
+            # pending backward() of an earlier evaluation stays where it is
+            return tet_spheres_ext.forward(x, self.tet_sp, c1, c2, order, fuse=False)
         return SmoothnessBarrierFunc.apply(x, self.tet_sp, c1, c2, order)

@@ -29,7 +29,7 @@ Deliberate differences from the reference (all listed in DESIGN.md):
   gradient on the ``TetSpheres`` object; the matching ``backward`` call only
   multiplies it by ``gradH``.  The cache key is ``(data_ptr, _version, shape, c1,
   c2, order)``; any miss recomputes, and every ``forward`` replaces or drops the
-  entry.  The key cannot see writes that bypass torch's version counter (``.data``
+  entry (except an explicit energy-only ``forward(..., fuse=False)``, which leaves it alone).  The key cannot see writes that bypass torch's version counter (``.data``
   ops, the raw-pointer ``AdamUniform`` step): the cache assumes that ``backward``
   follows ITS ``forward`` with no such write in between, which is what
   ``loss.backward()`` does.  The reference recomputes ``G x`` in backward (.cu:221).
@@ -115,8 +115,10 @@ class TetSpheres:
                                   max_threads=max_threads, target_owned=target_owned,
                                   balance_slots=int(balance_slots), num_threads=num_threads,
                                   debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread,
-                                  rebuild_dminv=int(REBUILD_DMINV if rebuild_dminv is None else rebuild_dminv)
-                                  if operator is None and slots_per_thread in (0, 2) else 0)
+                                  # (the environment default only applies where it can; an explicit True that cannot be
+                                  # honoured -- together with operator= -- is rejected by the library, not ignored)
+                                  rebuild_dminv=int(REBUILD_DMINV and operator is None) if rebuild_dminv is None
+                                  else int(bool(rebuild_dminv)))
         if isinstance(vertices, (str, os.PathLike)) and elements is None:
             if operator is not None:
                 raise TypeError("operator= needs the (vertices, elements) constructor")
@@ -215,8 +217,13 @@ def _cache_key(x: torch.Tensor, c1: float, c2: float, order: int):
     return (x.data_ptr(), x._version, x.shape, float(c1), float(c2), int(order))
 
 
-def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, order: int) -> torch.Tensor:
-    """Energy ``c1 * 1/2 |L G x|^2 + c2 * sum_e max(-det F_e, 0)^order`` (tet_spheres_cuda.cu:118-195)."""
+def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, order: int, *,
+            fuse: bool | None = None) -> torch.Tensor:
+    """Energy ``c1 * 1/2 |L G x|^2 + c2 * sum_e max(-det F_e, 0)^order`` (tet_spheres_cuda.cu:118-195).
+
+    ``fuse`` (keyword-only, not in the reference): ``None`` = ``tet_sph.fuse_forward_backward``; ``False`` = energy only,
+    whatever ``input.requires_grad`` says (logging / validation calls); such a call leaves a fused gradient kept for a
+    pending ``backward`` alone."""
     h = tet_sph._handle()
     x = _check_input(input, tet_sph)
     energy = torch.empty((), dtype=torch.float32, device=x.device)
@@ -224,13 +231,17 @@ def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, orde
     # (no torch.cuda.device() guard: the library switches to the handle's device itself)
     # (grad mode cannot be consulted here: inside autograd.Function.forward it is always off.  Callers that evaluate
     # under torch.no_grad() switch the fusion off themselves -- SmoothnessBarrierEnergy.forward does.)
-    if input.requires_grad and tet_sph.fuse_forward_backward:
+    if input.requires_grad and (tet_sph.fuse_forward_backward if fuse is None else fuse):
         g = torch.empty_like(x)
         _capi.check(_lib.tsamd_forward_backward(h, x.data_ptr(), None, c1, c2, int(order), stream,
                                                 energy.data_ptr(), g.data_ptr()))
         tet_sph._cache = (_cache_key(input, c1, c2, order), g)
     else:
-        tet_sph._cache = None
+        # An explicit energy-only call (fuse=False: logging / validation) leaves a kept gradient alone -- placed between
+        # `loss = energy(x)` and `loss.backward()` it must not cost that backward a second full pass.  Every other
+        # non-fused evaluation drops the entry, as before.
+        if fuse is None:
+            tet_sph._cache = None
         _capi.check(_lib.tsamd_forward(h, x.data_ptr(), c1, c2, int(order), stream, energy.data_ptr()))
     if CPU_ENERGY:
         return energy.cpu()                             # the reference's convention, .cu:194
