@@ -238,3 +238,169 @@ done:
     free(dminv); free(F); free(H); free(nbr);
     return rc;
 }
+
+/*
+ * Statistical model of the fp32 rounding error of a FACTORED evaluation -- plain-C twin of
+ * oracle/tet_energy_oracle.py::rounding_error_model (same formulas, uniform element Laplacian), fast enough for
+ * the 21 M-tet scene.  Every fp32 operation gets an independent relative error of standard deviation u = 2^-24;
+ * variances are pushed through F = Ds Dm^-1, H = L F, Q = L^T H, P = c1 Q + c2 pen' cof F, d = P Dm^-T and the
+ * per-vertex sums.  out_std_E: predicted standard deviation (+ second-order bias) of the energy error;
+ * out_std_g[n]: predicted standard deviation of every vertex' gradient error (Euclidean norm, grad_output = 1).
+ * Not a restatement of reference code: it is the yardstick the GPU parity tests hold the measured errors against.
+ */
+int tso_rounding_model(int64_t n, int64_t m, const float *rest, const int32_t *tets, const int32_t *nbr_in,
+                       const float *x, float c1f, float c2f, int order, double *out_std_E, double *out_std_g)
+{
+    const double u2 = ldexp(1.0, -48);
+    const double c1 = (double)c1f, c2 = (double)c2f;
+    double *dminv = NULL, *F = NULL, *H = NULL;
+    float *vF = NULL, *vH = NULL;
+    int32_t *nbr = NULL;
+    int64_t e;
+    int rc = 0, i, j, k;
+    double Es = 0.0, Eb = 0.0, sHHvH = 0.0, sH4 = 0.0, sdpvJ = 0.0, spen2 = 0.0, svH = 0.0;
+
+    dminv = (double *)malloc(sizeof(double) * 9 * (size_t)(m ? m : 1));
+    F = (double *)malloc(sizeof(double) * 9 * (size_t)(m ? m : 1));
+    H = (double *)malloc(sizeof(double) * 9 * (size_t)(m ? m : 1));
+    vF = (float *)malloc(sizeof(float) * 9 * (size_t)(m ? m : 1));
+    vH = (float *)malloc(sizeof(float) * 9 * (size_t)(m ? m : 1));
+    nbr = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)(m ? m : 1));
+    if (!dminv || !F || !H || !vF || !vH || !nbr) { rc = 1; goto done; }
+    if (nbr_in) memcpy(nbr, nbr_in, sizeof(int32_t) * 4 * (size_t)m);
+    else if ((rc = tso_face_adjacency(m, tets, nbr)) != 0) goto done;
+    if ((rc = tso_rest_inverse(m, rest, tets, 1, dminv)) != 0) goto done;
+
+#pragma omp parallel for private(i, j, k) schedule(static)
+    for (e = 0; e < m; e++) {                 /* F and var F */
+        const int32_t *t = tets + 4 * e;
+        double Ds[9];
+        for (i = 0; i < 3; i++)
+            for (k = 0; k < 3; k++)
+                Ds[3 * i + k] = (double)x[3 * t[k + 1] + i] - (double)x[3 * t[0] + i];
+        for (i = 0; i < 3; i++)
+            for (j = 0; j < 3; j++) {
+                double s = 0.0, v = 0.0;
+                for (k = 0; k < 3; k++) {
+                    const double p = Ds[3 * i + k] * dminv[9 * e + 3 * k + j];
+                    s += p;
+                    v += p * p;
+                }
+                F[9 * e + 3 * i + j] = s;
+                vF[9 * e + 3 * i + j] = (float)(u2 * v);
+            }
+    }
+#pragma omp parallel for private(i, k) reduction(+ : Es, sHHvH, sH4, svH) schedule(static)
+    for (e = 0; e < m; e++) {                 /* H = L F, var H (L o L: deg^2 on the diagonal, 1 off it) */
+        int deg = 0;
+        double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (k = 0; k < 4; k++) {
+            int32_t q = nbr[4 * e + k];
+            if (q < 0) continue;
+            deg++;
+            for (i = 0; i < 9; i++) {
+                h[i] -= F[9 * q + i];
+                v[i] += (double)vF[9 * q + i] + u2 * F[9 * q + i] * F[9 * q + i];
+            }
+        }
+        for (i = 0; i < 9; i++) {
+            const double f = F[9 * e + i], d2 = (double)deg * deg;
+            h[i] += deg * f;
+            v[i] += d2 * ((double)vF[9 * e + i] + u2 * f * f);
+            H[9 * e + i] = h[i];
+            vH[9 * e + i] = (float)v[i];
+            Es += 0.5 * h[i] * h[i];
+            sHHvH += h[i] * h[i] * v[i];
+            sH4 += h[i] * h[i] * h[i] * h[i];
+            svH += v[i];
+        }
+    }
+    for (i = 0; i < n; i++) out_std_g[i] = 0.0;
+#pragma omp parallel for private(i, j, k) reduction(+ : Eb, sdpvJ, spen2) schedule(static)
+    for (e = 0; e < m; e++) {
+        const int32_t *t = tets + 4 * e;
+        const double *f = F + 9 * e, *di = dminv + 9 * e;
+        int deg = 0;
+        double Q[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, vQ[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double C[9], vC[9], J, Jm, pen = 0.0, dpen = 0.0, ddpen = 0.0, vJ = 0.0, Pm[9], vP[9], d[9], vd[9];
+        for (k = 0; k < 4; k++) {
+            int32_t q = nbr[4 * e + k];
+            if (q < 0) continue;
+            deg++;
+            for (i = 0; i < 9; i++) {
+                Q[i] -= H[9 * q + i];
+                vQ[i] += (double)vH[9 * q + i] + u2 * H[9 * q + i] * H[9 * q + i];
+            }
+        }
+        for (i = 0; i < 9; i++) {
+            const double h = H[9 * e + i], d2 = (double)deg * deg;
+            Q[i] += deg * h;
+            vQ[i] += d2 * ((double)vH[9 * e + i] + u2 * h * h);
+        }
+        J = det3(f);
+        Jm = J < 0 ? -J : 0.0;
+        if (order == 2) { pen = Jm * Jm; dpen = J < 0 ? -2.0 * Jm : 0.0; ddpen = J < 0 ? 2.0 : 0.0; }
+        else if (order == 4) { pen = Jm * Jm * Jm * Jm; dpen = J < 0 ? -4.0 * Jm * Jm * Jm : 0.0; ddpen = J < 0 ? 12.0 * J * J : 0.0; }
+        cof3(f, C);
+        for (i = 0; i < 9; i++) vJ += C[i] * C[i] * (double)vF[9 * e + i];
+        {   /* the six triple products of det, each with its own rounding */
+            const double a = f[2] * f[4] * f[6], b = f[1] * f[5] * f[6], c = f[2] * f[3] * f[7], dd = f[0] * f[5] * f[7],
+                         ee = f[1] * f[3] * f[8], ff = f[0] * f[4] * f[8];
+            vJ += u2 * (a * a + b * b + c * c + dd * dd + ee * ee + ff * ff);
+        }
+        for (i = 0; i < 3; i++)               /* cofactor entries C_ij = F_a F_d - F_b F_c */
+            for (j = 0; j < 3; j++) {
+                const int r0 = i == 0 ? 1 : 0, r1 = i == 2 ? 1 : 2, c0 = j == 0 ? 1 : 0, c1i = j == 2 ? 1 : 2;
+                const double Fa = f[3 * r0 + c0], Fd = f[3 * r1 + c1i], Fb = f[3 * r0 + c1i], Fc = f[3 * r1 + c0];
+                const double va = vF[9 * e + 3 * r0 + c0], vdd = vF[9 * e + 3 * r1 + c1i], vb = vF[9 * e + 3 * r0 + c1i],
+                             vc = vF[9 * e + 3 * r1 + c0];
+                vC[3 * i + j] = Fd * Fd * va + Fa * Fa * vdd + Fc * Fc * vb + Fb * Fb * vc + u2 * (Fa * Fd * Fa * Fd + Fb * Fc * Fb * Fc);
+            }
+        for (i = 0; i < 9; i++) {
+            const double vPb = ddpen * ddpen * vJ * C[i] * C[i] + dpen * dpen * vC[i] + u2 * dpen * C[i] * dpen * C[i];
+            Pm[i] = c1 * Q[i] + c2 * dpen * C[i];
+            vP[i] = c1 * c1 * vQ[i] + c2 * c2 * vPb + u2 * Pm[i] * Pm[i];
+        }
+        for (i = 0; i < 3; i++)
+            for (k = 0; k < 3; k++) {
+                double s = 0.0, v = 0.0;
+                for (j = 0; j < 3; j++) {
+                    const double w = di[3 * k + j];
+                    s += Pm[3 * i + j] * w;
+                    v += (vP[3 * i + j] + u2 * Pm[3 * i + j] * Pm[3 * i + j]) * w * w;
+                }
+                d[3 * i + k] = s;
+                vd[3 * i + k] = v;
+            }
+        {
+            double all_vd = 0.0, all_d2 = 0.0, f02 = 0.0;
+            for (k = 0; k < 3; k++) {
+                double sv = 0.0, sd2 = 0.0;
+                for (i = 0; i < 3; i++) { sv += vd[3 * i + k]; sd2 += d[3 * i + k] * d[3 * i + k]; }
+#pragma omp atomic
+                out_std_g[t[k + 1]] += sv + u2 * sd2;
+                all_vd += sv;
+                all_d2 += sd2;
+            }
+            for (i = 0; i < 3; i++) {
+                const double f0 = -(d[3 * i] + d[3 * i + 1] + d[3 * i + 2]);
+                f02 += f0 * f0;
+            }
+#pragma omp atomic
+            out_std_g[t[0]] += all_vd + u2 * f02 + u2 * all_d2;
+        }
+        Eb += pen;
+        sdpvJ += dpen * dpen * vJ;
+        spen2 += pen * pen;
+    }
+    for (i = 0; i < n; i++) out_std_g[i] = sqrt(out_std_g[i]);
+    {
+        const double part = m > 1024 ? 1024.0 / (double)m : 1.0;
+        const double vE = c1 * c1 * (sHHvH + 4 * u2 * Es * Es * part + u2 * 0.25 * sH4)
+                        + c2 * c2 * (sdpvJ + u2 * spen2 + 4 * u2 * Eb * Eb * part);
+        *out_std_E = sqrt(vE) + c1 * 0.5 * svH;
+    }
+done:
+    free(dminv); free(F); free(H); free(vF); free(vH); free(nbr);
+    return rc;
+}

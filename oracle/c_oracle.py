@@ -31,6 +31,10 @@ def _load():
         lib.tso_energy_grad.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float,
                                         ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
+        lib.tso_rounding_model.restype = ctypes.c_int
+        lib.tso_rounding_model.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_float,
+                                           ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -58,3 +62,20 @@ def energy_and_grad(rest, tets, x, c1, c2, order, grad_output=1.0, want_grad=Tru
     if rc:
         raise ValueError(f"tso_energy_grad failed with code {rc}")
     return float(E[0]), float(E[1]), float(E[2]), g
+
+
+def rounding_error_model(rest, tets, x, c1, c2, order, nbr=None):
+    """``(std_E, std_g[n])`` -- the plain-C twin of ``tet_energy_oracle.rounding_error_model`` (uniform element
+    Laplacian), for scenes the numpy model cannot hold in memory."""
+    rest = np.ascontiguousarray(rest, dtype=np.float32).reshape(-1, 3)
+    t = np.ascontiguousarray(tets, dtype=np.int32).reshape(-1, 4)
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3)
+    std_e = np.zeros(1)
+    std_g = np.empty(rest.shape[0])
+    nb = None if nbr is None else np.ascontiguousarray(nbr, dtype=np.int32)
+    rc = _load().tso_rounding_model(rest.shape[0], t.shape[0], rest.ctypes.data, t.ctypes.data,
+                                    None if nb is None else nb.ctypes.data, x.ctypes.data,
+                                    float(c1), float(c2), int(order), std_e.ctypes.data, std_g.ctypes.data)
+    if rc:
+        raise ValueError(f"tso_rounding_model failed with code {rc}")
+    return float(std_e[0]), std_g

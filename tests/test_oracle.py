@@ -222,3 +222,79 @@ def test_libpgo_pin_if_present(golden_dir):
     assert str(z["winner"]) == "uniform", "libpgo's operator is not the one this library assumes by default"
     M, _ = O.biharmonic_matrix(rest, tets, n)
     assert abs(M - M_pgo).max() <= 1e-9 * abs(M_pgo).max()
+
+
+@pytest.mark.parametrize("kind,S,sigma,order", [("kuhn8", 4, 0.3, 2), ("kuhn8", 3, 0.02, 4), ("kuhn6", 2, 0.0, 2),
+                                               ("delaunay700", 2, 0.3, 4), ("cone", 1, 0.3, 2)])
+def test_c_rounding_model_equals_numpy_model(kind, S, sigma, order):
+    """oracle/c tso_rounding_model is the yardstick of the full-size GPU tests: it must be the numpy model
+    (variances are stored in fp32 there: 1e-7 relative)."""
+    from oracle import c_oracle
+    from tssplat_amd import scenes
+    sc = scenes.make_scene(kind, S)
+    x = scenes.deform(sc, sigma)
+    c1, c2 = 2e-4 / S, 2e-4
+    cache = O.prepare(sc.rest, sc.tets)
+    se, sg = O.rounding_error_model(x, cache, c1, c2, order)
+    se2, sg2 = c_oracle.rounding_error_model(sc.rest, sc.tets, x, c1, c2, order)
+    assert abs(se - se2) <= 1e-6 * se
+    assert np.all(np.abs(sg - sg2) <= 1e-6 * sg + 1e-300)
+
+
+# --------------------------------------------------------------------------- #
+# oracle/_ref: the reference's own det / ddetA_dA / penalty kernels (tet_spheres_cuda.cu:9-102), compiled for the host
+# --------------------------------------------------------------------------- #
+
+def _check_against_reference_kernels(F, det32, det64, cof32, cof64, fwd, bwd):
+    """The oracle's restatement of .cu:9-102 against outputs of the reference code itself.  The reference stores a
+    3x3 matrix column-major (`elt`, .cu:9-19), the oracle row-major: det is transpose-invariant and cof(A^T) = cof(A)^T,
+    so the same nine numbers go in and the same nine come out in either convention."""
+    F64 = F.astype(np.float64).reshape(-1, 3, 3)
+    J = O.det3(F64)
+    C = O.cofactor3(F64).reshape(-1, 9)
+    scale_j = np.abs(F64).max(axis=(1, 2)) ** 3 + 1e-300
+    scale_c = np.abs(F64).max(axis=(1, 2))[:, None] ** 2 + 1e-300
+    assert np.all(np.abs(J - det64) <= 4e-16 * scale_j)             # same six products, double: rounding of the sums only
+    assert np.all(np.abs(C - cof64) <= 4e-16 * scale_c)
+    assert np.all(np.abs(J - det32) <= 4e-7 * scale_j)              # the fp32 instantiation the kernels use
+    assert np.all(np.abs(C - cof32) <= 4e-7 * scale_c)
+    for order in (2, 3, 4):
+        pen, dpen = O._penalty(J, order)
+        ref_pen, ref_dP = fwd[order].astype(np.float64), bwd[order].astype(np.float64)
+        if order == 3:                                              # neither 2 nor 4: the reference yields 0 (.cu:57-63, :86-91)
+            assert np.all(ref_pen == 0) and np.all(ref_dP == 0) and np.all(pen == 0) and np.all(dpen == 0)
+            continue
+        # fp32 kernels against the float64 restatement: first-order propagation of the fp32 error of det (4e-7 scale_j,
+        # asserted above) and of the cofactor entries (4e-7 scale_c) through J^order and pen'(J) cof F
+        Jm = np.maximum(-J, 0.0) + 4e-7 * scale_j
+        dJ, dC = 4e-7 * scale_j, 4e-7 * scale_c
+        assert np.all(np.abs(pen - ref_pen) <= 2 * order * Jm ** (order - 1) * dJ + 1e-6 * pen)
+        dP = dpen[:, None] * C                                      # d pen / dF = pen'(J) cof F   (.cu:93-95)
+        tol_dP = 2 * (order * (order - 1) * Jm ** (order - 2) * dJ)[:, None] * (np.abs(C) + dC) + 2 * (order * Jm ** (order - 1))[:, None] * dC \
+            + 1e-6 * np.abs(dP)
+        assert np.all(np.abs(dP - ref_dP) <= tol_dP)
+        assert np.all((ref_dP != 0).any(axis=1) <= (det32 < 0))     # zero unless inverted (.cu:97-101)
+
+
+def test_det_cofactor_penalty_against_reference_golden():
+    """Committed outputs of the reference's own kernels (tests/golden/make_ref_det_golden.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_det_golden.npz"))
+    assert int((g["det_f64"] < 0).sum()) > 50                       # the penalty branch is exercised
+    _check_against_reference_kernels(g["F"], g["det_f32"], g["det_f64"], g["cof_f32"], g["cof_f64"],
+                                     {k: g[f"fwd{k}"] for k in (2, 3, 4)}, {k: g[f"bwd{k}"] for k in (2, 3, 4)})
+
+
+def test_det_cofactor_penalty_against_oracle_ref_live():
+    """oracle/_ref/libref_det.so itself (built from /root/reference where it lies; travels to the GPU box), on fresh
+    random matrices -- and it reproduces the committed golden bit for bit."""
+    from oracle import ref_det
+    if not ref_det.available():
+        pytest.skip("oracle/_ref is not built and /root/reference is not present")
+    rng = np.random.default_rng(99)
+    F = (np.eye(3).reshape(1, 9) + 0.8 * rng.standard_normal((500, 9))).astype(np.float32)
+    _check_against_reference_kernels(F, ref_det.det(F), ref_det.det(F.astype(np.float64)), ref_det.ddetA_dA(F),
+                                     ref_det.ddetA_dA(F.astype(np.float64)),
+                                     {k: ref_det.forward_det(F, k) for k in (2, 3, 4)},
+                                     {k: ref_det.backward_det(F, k) for k in (2, 3, 4)})
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_det_golden.npz"))
+    assert np.array_equal(ref_det.det(g["F"]), g["det_f32"]) and np.array_equal(ref_det.backward_det(g["F"], 4), g["bwd4"])
