@@ -64,15 +64,25 @@ def parse(argv=None):
     p.add_argument("--order", type=int, default=2)
     p.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                    help="auto = strong (the fixed 512-sphere scene split over the ranks)")
-    p.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
-                   help="auto = whichever of the two is faster on this batch (measured during setup)")
+    p.add_argument("--launch", choices=["auto", "graph", "eager", "graph-autograd"], default="auto",
+                   help="auto = graph replay or eager autograd, whichever is faster on this batch (measured during setup); "
+                        "graph-autograd = SmoothnessBarrierEnergy(graph=True) + backward(): the replay behind an autograd node")
     p.add_argument("--max-threads", type=int, default=0)
     p.add_argument("--lds-budget", type=int, default=0)
     p.add_argument("--target-owned", type=int, default=0)
     p.add_argument("--spt", type=int, default=0, help="slots per thread (2 or 4; 0 = library default)")
     p.add_argument("--rebuild-dminv", type=int, default=-1, help="1 = rebuild Dm^-1 in registers from rest positions, 0 = stream it, -1 = library default")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-spheres", type=int, default=8)
+    p.add_argument("--cpu-sample-spheres", type=int, default=0,
+                   help="spheres of the SAME scene (the first K, same seeds) the CPU baseline is timed on; 0 = the whole scene "
+                        "up to ~2.7 M tets (64 x kuhn19, all of 64/256 x kuhn8)")
+    p.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline; 0 = min(16, host cores)")
+    p.add_argument("--force-collective", action="store_true",
+                   help="N = 1 only: create a single-rank process group and issue the per-step energy exchange exactly as the "
+                        "N > 1 path does, so that its host cost is inside the timed loop (scaling model, tools/scaling_model.py)")
+    p.add_argument("--energy-window", type=int, default=16,
+                   help="N > 1: the local energies of this many steps go into a ring of device slots and are all-reduced with ONE "
+                        "collective per window (1 = one all-reduce per step)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (bring-up on a 1-GPU box)")
     p.add_argument("--all-ranks-on-device0", action="store_true",
                    help="bring-up only: every rank uses cuda:0 (needs --dist-backend gloo)")
@@ -82,54 +92,63 @@ def parse(argv=None):
     return p.parse_args(argv)
 
 
-def cpu_baseline(args, torch, scenes):
+def _cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, torch, scenes, sample, x_sample, c1, c2, total_spheres):
     """The reference *formulation* (fp32 sparse M = G^T L^T L G and G, five sparse products per
-    forward+backward, tet_spheres_cuda.cu:118-263) in plain PyTorch on the host cores, on a
-    bounded sample of the same workload.  Oracle-side code, timed as the baseline only."""
+    forward+backward, tet_spheres_cuda.cu:118-263) in plain PyTorch on the host cores, on the SAME inputs as the GPU leg:
+    the first K spheres of the same scene with the same deformed positions and coefficients (all of them where the scene
+    is small enough).  Oracle-side code, timed as the baseline only."""
     from oracle import torch_energies as TE
-    S = max(1, min(args.cpu_sample_spheres, args.spheres))
-    sc = scenes.make_scene(args.scene, S, seed=0)
+    sc = sample
     t0 = time.time()
     ts = TE.TorchTetSpheres(sc.rest, sc.tets, layout="csr")
     build_s = time.time() - t0
-    x = torch.from_numpy(scenes.deform(sc, args.sigma, seed=1))
-    c1, c2 = 2e-4 / args.spheres, 2e-4
+    x = torch.from_numpy(x_sample)
 
     def one():
         TE.compute_energy(x, ts, c1, c2, args.order)
         TE.compute_energy_backward(1.0, x, ts, c1, c2, args.order)
 
-    # torch's sparse CSR kernels do not scale with threads; pick the best of a short sweep so the
-    # baseline is not handicapped by oversubscription, then time that setting
     ncpu = os.cpu_count() or 1
-    best_threads, best_rate = torch.get_num_threads(), 0.0
+    fixed = args.cpu_threads if args.cpu_threads > 0 else min(16, ncpu)
+    # secondary: a short thread sweep (torch's sparse CSR kernels do not scale with threads)
+    sweep = {}
     for nt in sorted({1, 4, 8, 16, 32, ncpu} & set(range(1, ncpu + 1))):
         torch.set_num_threads(nt)
         one()
         t0 = time.time()
-        for _ in range(3):
-            one()
-        rate = 3 / (time.time() - t0)
-        if rate > best_rate:
-            best_threads, best_rate = nt, rate
-    torch.set_num_threads(best_threads)
-    for _ in range(2):
         one()
+        sweep[str(nt)] = sc.n_tets / (time.time() - t0)
+    torch.set_num_threads(fixed)
+    one()
     reps, t0 = 0, time.time()
     while True:
         one()
         reps += 1
         el = time.time() - t0
-        if (reps >= 30 and el > 5.0) or el > 15.0:
+        if (reps >= 10 and el > 10.0) or el > 25.0:
             break
     return {
         "value": sc.n_tets * reps / el,
         "unit": "tets/s",
-        "cores": int(best_threads),
+        "cores": int(fixed),
         "kind": "port",
-        "sample": f"{S} x {args.scene} spheres ({sc.n_tets} tets), {reps} fwd+bwd evaluations in {el:.1f} s, "
-                  f"torch sparse CSR fp32 (reference formulation M=G'L'LG + G, tet_spheres_cuda.cu:118-263), best of a "
-                  f"thread sweep on {ncpu} host cores, operator build {build_s:.1f} s untimed",
+        "cpu_model": _cpu_model(),
+        "host_cores": ncpu,
+        "sample": f"spheres 0..{sc.n_spheres - 1} of the GPU leg's {total_spheres} x {args.scene} scene (seed 0; same rest mesh, same "
+                  f"deformed positions sigma={args.sigma} seed 1, same c1/c2/order): {sc.n_tets} tets, {reps} fwd+bwd evaluations in "
+                  f"{el:.1f} s at {fixed} torch threads, torch sparse CSR fp32 (reference formulation M=G'L'LG + G, "
+                  f"tet_spheres_cuda.cu:118-263), operator build {build_s:.1f} s untimed",
+        "thread_sweep_tets_per_s": sweep,
     }
 
 
@@ -195,8 +214,14 @@ def _run_rank(args, stdout_fd: int) -> None:
     if use_gpu:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # --force-collective at N = 1: a single-rank group, so that every step pays the host cost of the energy exchange
+    use_coll = world > 1 or (args.force_collective and not args.dry_run)
+    if use_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = "gloo" if args.dry_run else args.dist_backend
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -227,10 +252,14 @@ def _run_rank(args, stdout_fd: int) -> None:
     if args.dry_run:
         # plumbing only: a fake local energy, the real collective and check, fake timing
         e_local = torch.tensor([float(my_spheres)])
-        red = e_local.clone()
-        work = dist.all_reduce(red, async_op=True) if world > 1 else None
-        if work is not None:
-            work.wait()
+        # the same windowed exchange as the timed loop (tssplat_amd/sharding.py), a few fake steps
+        from tssplat_amd.sharding import WindowedEnergyAllReduce
+        reducer = WindowedEnergyAllReduce(max(1, args.energy_window), "cpu")
+        for _ in range(max(args.steps, 1)):
+            reducer.push(e_local)
+        red_all = reducer.results()
+        assert red_all.numel() == max(args.steps, 1) and bool((red_all == red_all[0]).all())
+        red = red_all[-1:].clone()
         parts = [torch.zeros(1) for _ in range(world)]
         if world > 1:
             dist.all_gather(parts, e_local)
@@ -266,11 +295,26 @@ def _run_rank(args, stdout_fd: int) -> None:
     info = energy.tet_sp.plan_info()
     if rank == 0:
         log(f"rank 0: {my_spheres} x {args.scene}: n={sc.n_vertices} m={sc.n_tets}; plan {t_plan:.1f} s: {info}")
-    x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, args.sigma, seed=seed + 1)).to(dev))
+    x_host = scenes.deform(sc, args.sigma, seed=seed + 1)
+    x = torch.nn.Parameter(torch.from_numpy(x_host).to(dev))
     m_local, n_local = sc.n_tets, sc.n_vertices
-    del sc
+    cpu_sample = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        # the CPU baseline runs on the same inputs: the first K spheres of this very scene, with these positions
+        tets_per_sphere = max(m_local // max(my_spheres, 1), 1)
+        k = args.cpu_sample_spheres if args.cpu_sample_spheres > 0 else max(1, min(my_spheres, 2_700_000 // tets_per_sphere))
+        k = min(k, my_spheres)
+        sub = sc.slice_spheres(0, k)
+        cpu_sample = (sub, x_host[:sub.n_vertices].copy())
+    del sc, x_host
 
-    it = 10
+    it0 = 10
+
+    def coeffs(i):
+        # the reference's schedule moves the coefficients every iteration (smooth_barrier.py:47-58): a timed step does too
+        return energy.coeff_scheduler(it0 + i % 900)
+
+    it = it0
     c1, c2 = energy.coeff_scheduler(it)
     from tssplat_amd import _capi
     lib = _capi.load()
@@ -294,7 +338,7 @@ def _run_rank(args, stdout_fd: int) -> None:
             raw()
 
     graphed = None
-    if args.launch in ("auto", "graph"):
+    if args.launch in ("auto", "graph", "graph-autograd"):
         try:
             graphed = GraphedSmoothnessBarrier(energy, x)
             graphed.step(it)
@@ -303,30 +347,41 @@ def _run_rank(args, stdout_fd: int) -> None:
             log(f"HIP graph capture failed ({exc!r}); using --launch eager")
             graphed = None
 
-    if world > 1 and args.launch in ("auto", "graph"):   # every rank must take the same path through the probes below
+    if world > 1 and args.launch in ("auto", "graph", "graph-autograd"):   # every rank must take the same path through the probes below
         ok = torch.tensor([1 if graphed is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             graphed = None
 
-    pending = []
+    from tssplat_amd.sharding import WindowedEnergyAllReduce
+    reducer = WindowedEnergyAllReduce(max(1, args.energy_window), dev) if use_coll else None
 
-    def step_eager():
+    def step_eager(i):
         x.grad = None
-        e = energy(x, it, c1, c2)          # fused energy+gradient pass, finish kernel
-        e.backward()                        # grad_output scale
+        a, b = coeffs(i)
+        e = energy(x, it0 + i % 900, a, b)   # fused energy+gradient pass, finish kernel
+        e.backward()                          # grad_output scale
         return e.detach()
 
-    def step_graph():
-        return graphed.step(it)[0]
+    def step_graph(i):
+        return graphed.step(it0 + i % 900)[0]            # (coefficients refreshed on the device whenever they change: every step here)
 
-    def step(fn):
-        e = fn()
-        if world > 1:                       # the path's only exchange: the scalar energy (never on the gradient's path)
-            red = e.clone().reshape(1)
-            pending.append((red, dist.all_reduce(red, op=dist.ReduceOp.SUM, async_op=True)))
-            if len(pending) > 4:
-                pending.pop(0)[1].wait()
+    def step_graph_autograd(i):
+        # code shaped like the reference trainer (trainer.py:94-130), replayed: SmoothnessBarrierEnergy(graph=True)
+        x.grad = None
+        a, b = coeffs(i)
+        energy.graph = True
+        try:
+            e = energy(x, it0 + i % 900, a, b)
+        finally:
+            energy.graph = False
+        e.backward()
+        return e.detach()
+
+    def step(fn, i):
+        e = fn(i)
+        if reducer is not None:             # the path's only exchange: the scalar energy (never on the gradient's path)
+            reducer.push(e)
         return e
 
     def fence():
@@ -336,12 +391,16 @@ def _run_rank(args, stdout_fd: int) -> None:
         torch.cuda.synchronize(dev)
 
     def timed(fn, steps, warmup):
-        for _ in range(warmup):
-            step(fn)
+        for i in range(warmup):
+            step(fn, i)
+        if reducer is not None:
+            reducer.results()               # (warm-up energies are not part of the check below)
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            e = step(fn)
+        for i in range(steps):
+            e = step(fn, warmup + i)
+        if reducer is not None:
+            reducer.flush()                 # the last (partial) window's collective is issued inside the timed region
         fence()
         el = time.perf_counter() - t0
         if world > 1:
@@ -356,33 +415,40 @@ def _run_rank(args, stdout_fd: int) -> None:
         for name, fn in (("graph", step_graph), ("eager", step_eager)):
             preheat()
             probe[name] = timed(fn, 10, 3)[0] / 10
+            if reducer is not None:
+                reducer.results()
         # (replay only where it clearly wins: on the 21 M-tet scene the two are within the probe's noise)
         pick = torch.tensor([0 if probe["graph"] <= 0.95 * probe["eager"] else 1], device=dev)
         if world > 1:
             dist.broadcast(pick, src=0)
         launch_mode = "graph" if int(pick.item()) == 0 else "eager"
-    main_fn = step_graph if launch_mode == "graph" else step_eager
+    main_fn = {"graph": step_graph, "eager": step_eager, "graph-autograd": step_graph_autograd}[launch_mode]
     preheat()
     elapsed, e_last = timed(main_fn, args.steps, args.warmup)
     e_val = float(e_last)
     # the collective's result = sum of the rank energies (checked, not just issued)
     e_global = e_val
-    if world > 1:
-        for red, work in pending:
-            work.wait()
-        e_global = float(pending[-1][0])
+    if reducer is not None:
+        reduced = reducer.results()
+        assert reduced.numel() == args.steps, (reduced.numel(), args.steps)
+        e_global = float(reduced[-1])
         parts = [torch.zeros(1, device=dev) for _ in range(world)]
-        dist.all_gather(parts, e_last.clone().reshape(1))
+        if world > 1:
+            dist.all_gather(parts, e_last.clone().reshape(1))
+        else:
+            parts = [e_last.clone().reshape(1)]
         e_sum = sum(float(p) for p in parts)
         assert abs(e_global - e_sum) <= 1e-5 * abs(e_sum) + 1e-30, f"all-reduced energy {e_global} != sum of rank energies {e_sum}"
-    pending.clear()
 
-    other = None
-    if world == 1:                                     # the other launch mode, for the record
-        other_fn = step_eager if launch_mode == "graph" else (step_graph if graphed is not None else None)
-        if other_fn is not None:
+    others = {}
+    if world == 1:                                     # the other launch modes, for the record
+        for name, fn in (("eager_autograd", step_eager), ("graph_replay", step_graph), ("graph_autograd", step_graph_autograd)):
+            if fn is main_fn or (graphed is None and fn is not step_eager):
+                continue
             preheat()
-            other = timed(other_fn, args.steps, min(args.warmup, 5))[0]
+            others[name + "_ms_per_step"] = 1e3 * timed(fn, args.steps, min(args.warmup, 5))[0] / args.steps
+            if reducer is not None:
+                reducer.results()
 
     # ---- roofline leg: the tile kernel alone, HIP events on the launch stream (raw C-ABI evaluations) ----
     preheat()
@@ -439,8 +505,13 @@ def _run_rank(args, stdout_fd: int) -> None:
                 "workload": f"{total_spheres} tet-spheres x {args.scene} ({total_tets} tets total, "
                             f"{m_local} tets / {n_local} vertices on rank 0), sigma={args.sigma}, order={args.order}, "
                             f"energy + full gradient per step",
-                "launch": ("HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier)" if launch_mode == "graph"
-                           else "eager: SmoothnessBarrierEnergy + backward() through torch.autograd"),
+                "launch": {"graph": "HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier.step)",
+                           "eager": "eager: SmoothnessBarrierEnergy + backward() through torch.autograd",
+                           "graph-autograd": "SmoothnessBarrierEnergy(graph=True) + backward(): HIP-graph replay behind an autograd node"}[launch_mode],
+                "schedule": "coefficients follow coeff_scheduler(it) and change every step (one 8-byte H2D refresh per replay)",
+                "energy_exchange": (f"per-step local energies into a ring of {reducer.window} device slots, one all-reduce per window "
+                                    f"({reducer.collectives} collectives so far, backend {dist.get_backend()}, {dist.get_world_size()} rank(s))"
+                                    if reducer is not None else "none (one rank, no process group)"),
                 "spheres_rank0": my_spheres,
                 "tets_rank0": m_local,
                 "vertices_rank0": n_local,
@@ -467,12 +538,10 @@ def _run_rank(args, stdout_fd: int) -> None:
             "energy": e_global,
             "plan_build_s": t_plan,
         }
-        if other is not None:
-            key = "eager_autograd_ms_per_step" if launch_mode == "graph" else "graph_replay_ms_per_step"
-            out[key] = 1e3 * other / args.steps
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, torch, scenes)
-    if world > 1:
+        out.update(others)
+        if cpu_sample is not None:
+            out["cpu_baseline"] = cpu_baseline(args, torch, scenes, cpu_sample[0], cpu_sample[1], c1, c2, total_spheres)
+    if use_coll:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -184,3 +184,42 @@ def test_scene_slices_are_self_contained():
     part = sc.slice_spheres(1, 4)
     assert part.n_spheres == 3 and part.tets.min() == 0 and part.tets.max() == part.n_vertices - 1
     assert np.array_equal(part.rest, sc.rest[sc.sphere_vertex_offsets[1]:sc.sphere_vertex_offsets[4]])
+
+
+def _window_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tssplat_amd.sharding import WindowedEnergyAllReduce
+        red = WindowedEnergyAllReduce(8, "cpu")
+        for i in range(37):                                   # four full windows + a partial one
+            red.push(torch.tensor(float((rank + 1) * 1000 + i)))
+        first = red.results()
+        for i in range(3):                                    # reusable after results()
+            red.push(torch.tensor(float(rank + i)))
+        out[rank] = (first.numpy().copy(), red.results().numpy().copy(), red.collectives)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_windowed_energy_all_reduce_two_ranks():
+    """One collective per window of steps instead of one per step: reduced values, order,
+    partial windows, reuse."""
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_window_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        for rank in range(world):
+            first, second, ncoll = out[rank]
+            assert np.array_equal(first, np.array([1000 + 2000 + 2 * i for i in range(37)], dtype=np.float32))
+            assert np.array_equal(second, np.array([0 + 1 + 2 * i for i in range(3)], dtype=np.float32))
+            assert ncoll == 5 + 1                              # ceil(37 / 8) + the partial window of 3
+
+
+def test_windowed_energy_all_reduce_without_process_group():
+    from tssplat_amd.sharding import WindowedEnergyAllReduce
+    red = WindowedEnergyAllReduce(4, "cpu")
+    for i in range(10):
+        red.push(torch.tensor(float(i)))
+    assert np.array_equal(red.results().numpy(), np.arange(10, dtype=np.float32)) and red.collectives == 0

@@ -60,8 +60,12 @@ def main():
     print(f"operator built in {time.time() - t0:.1f} s, nnz {L.nnz}")
     measure(T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), operator=L), "explicit operator (same L as data)")
     for thr, lds in ((768, 81920), (640, 68000), (512, 54400), (448, 48000)):
-        measure(T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), operator=L, max_threads=thr, lds_budget_bytes=lds),
-                f"explicit, {thr} threads, {lds} B")
+        try:
+            ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), operator=L, max_threads=thr, lds_budget_bytes=lds)
+        except RuntimeError as exc:        # a thread count the explicit-operator kernels of this build are not compiled for
+            print(f"explicit, {thr} threads, {lds} B: {exc}")
+            continue
+        measure(ts, f"explicit, {thr} threads, {lds} B")
     measure(T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), max_threads=640, lds_budget_bytes=68000), "built-in, 640 threads / 68000 B")
 
 

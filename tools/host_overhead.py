@@ -48,3 +48,16 @@ def f_mod(i):
     x.grad = None
     en(x, i, 1e-4, 2e-4).backward()
 run("module call + backward()", f_mod)
+en_g = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=True)
+def f_mod_graph(i):
+    x.grad = None
+    en_g(x, i, 1e-4, 2e-4).backward()
+run("module(graph=True) call + backward()  [replay behind autograd]", f_mod_graph)
+def f_mod_graph_sched(i):
+    x.grad = None
+    c1, c2 = en_g.coeff_scheduler(i % 900)
+    en_g(x, i % 900, c1, c2).backward()
+run("same, coefficients from the schedule (change every step)", f_mod_graph_sched)
+from tssplat_amd.energies import GraphedSmoothnessBarrier
+gr = GraphedSmoothnessBarrier(en, x)
+run("GraphedSmoothnessBarrier.step(it) (no autograd)", lambda i: gr.step(i % 900))

@@ -322,7 +322,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU.  Plans with an explicit operator carry nine more
     // planes and their kernel needs 92 VGPRs (five waves per SIMD): 512-thread tiles of <= 54 400 B measured fastest
     // (64 x kuhn19: 0.096 ms against 0.111 ms for 768-thread tiles at one workgroup per CU, 0.119 ms for 640 x 2).
-    const bool small_tiles = op != nullptr;
+    const bool small_tiles = op != nullptr && kTileThreadsWeighted < kTileThreads;
     const int thread_cap = op != nullptr ? kTileThreadsWeighted : kTileThreads;
     if (opt.max_threads > thread_cap) {
         err = "max_threads exceeds what the tile kernels are compiled for (" + std::to_string(thread_cap) + ")";

@@ -62,8 +62,13 @@ constexpr int kPlanes = 13;
 // use at most 640 (92 VGPRs, five waves per SIMD).
 constexpr int kSlotsPerLane = 2;
 constexpr int kTileThreads = 768;
+#ifdef TSAMD_W768   // experiment: explicit-operator kernels at the built-in kernels' launch bounds (78 VGPRs, no spill)
+constexpr int kTileThreadsWeighted = 768;
+constexpr int kWavesWeighted = 6;
+#else
 constexpr int kTileThreadsWeighted = 640;
 constexpr int kWavesWeighted = 5;
+#endif
 // Plans built with an explicit element operator (build_plan's `op`) carry 9 more fp32 planes per slot:
 //   [13]      L[e, e]
 //   [14..17]  L[e, n_k]   row weights, in the slot's (possibly re-ordered) neighbour order -- pass 2, H = L F

@@ -11,8 +11,10 @@ copy in front of the replay whenever they change (never while they are constant)
 
 The result is the same energy and the same gradient as ``SmoothnessBarrierEnergy`` + ``backward()`` with
 ``grad_output = grad_scale``; it is written to ``self.energy`` / ``self.grad`` (static buffers, overwritten by
-every ``step``).  Nothing here goes through autograd: add ``self.grad`` to the parameter's ``.grad`` (or hand it
-to ``AdamUniform``) yourself.
+every ``step``).  ``step`` itself does not go through autograd: add ``self.grad`` to the parameter's ``.grad`` (or
+hand it to ``AdamUniform``) yourself.  For code shaped like the reference trainer (``loss = ... + energy(x, it, c1, c2)``,
+``loss.backward()``, /root/reference/trainer.py:94-130) ``SmoothnessBarrierEnergy(..., graph=True)`` wraps the same
+replay in an autograd node (``GraphReplayFunc``): the trainer keeps its shape and gets the replayed kernels.
 """
 from __future__ import annotations
 
@@ -21,7 +23,7 @@ import torch
 from .. import _capi, tet_spheres_ext
 from .smooth_barrier import SmoothnessBarrierEnergy
 
-__all__ = ["GraphedSmoothnessBarrier"]
+__all__ = ["GraphedSmoothnessBarrier", "GraphReplayFunc"]
 
 _lib = _capi.load()
 
@@ -55,6 +57,7 @@ class GraphedSmoothnessBarrier:
         self._scale = torch.full((1,), float(grad_scale), dtype=torch.float32, device=dev)
         self._graphs: dict[int, torch.cuda.CUDAGraph] = {}
         self._stream = torch.cuda.Stream(device=dev)
+        self.ticket = 0            # evaluations so far (GraphReplayFunc: a backward must belong to the latest one)
 
     def _launch(self, order: int) -> None:
         stream = tet_spheres_ext._stream_ptr(self.x.device)
@@ -74,12 +77,9 @@ class GraphedSmoothnessBarrier:
                 self._launch(order)
         return g
 
-    def step(self, it: int, c1: float | None = None, c2: float | None = None):
-        """One evaluation at iteration ``it``: coefficients from ``coeff_scheduler(it)`` unless given, order 4 after
-        ``FLAGS.increase_order_iter``.  Returns ``(energy, grad)`` -- the static device buffers."""
-        if c1 is None or c2 is None:
-            c1, c2 = self.module.coeff_scheduler(it)
-        order = 4 if it > self.module.FLAGS.increase_order_iter else 2
+    def evaluate(self, c1: float, c2: float, order: int):
+        """Replay the fused evaluation with these coefficients; returns the static ``(energy, grad)`` buffers
+        (``grad`` already multiplied by ``grad_scale``)."""
         if self._last != (c1, c2):
             k = self._ring_pos
             self._ring_pos = (k + 1) % len(self._ring)
@@ -97,3 +97,41 @@ class GraphedSmoothnessBarrier:
             g = self._graphs[order] = self._capture(order)
         g.replay()
         return self.energy, self.grad
+
+    def step(self, it: int, c1: float | None = None, c2: float | None = None):
+        """One evaluation at iteration ``it``: coefficients from ``coeff_scheduler(it)`` unless given, order 4 after
+        ``FLAGS.increase_order_iter``.  Returns ``(energy, grad)`` -- the static device buffers."""
+        if c1 is None or c2 is None:
+            c1, c2 = self.module.coeff_scheduler(it)
+        order = 4 if it > self.module.FLAGS.increase_order_iter else 2
+        return self.evaluate(c1, c2, order)
+
+
+class GraphReplayFunc(torch.autograd.Function):
+    """The autograd node of ``SmoothnessBarrierEnergy(..., graph=True)``: same ``apply(x, ., c1, c2, order)`` shape as
+    ``SmoothnessBarrierFunc`` (reference energies/smooth_barrier.py:9-31), with the evaluation replayed from a HIP graph.
+
+    forward: one replay (tile + finish kernels: energy AND the unscaled gradient, into static buffers), returns the
+    energy buffer (a fresh tensor object on the same storage -- valid until the next evaluation, like every output of a
+    graphed callable).  backward: ``grad_output * gradient`` -- one small elementwise kernel, no second evaluation, and a
+    fresh tensor, so ``x.grad`` never aliases the static buffer."""
+
+    @staticmethod
+    def forward(ctx, x_cur, graphed, c1, c2, order):
+        energy, grad = graphed.evaluate(c1, c2, order)
+        ctx.graphed = graphed
+        ctx.ticket = graphed.ticket = graphed.ticket + 1
+        return energy.detach()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None, None, None, None
+        graphed = ctx.graphed
+        if ctx.ticket != graphed.ticket:
+            raise RuntimeError("backward() of a graph-replayed energy after a newer evaluation overwrote its static gradient "
+                               "buffer: call backward() before the next forward, or use graph=False")
+        go = grad_output
+        if go.device != graphed.grad.device or go.dtype != torch.float32:
+            go = go.detach().to(device=graphed.grad.device, dtype=torch.float32, non_blocking=True)
+        return graphed.grad * go, None, None, None, None

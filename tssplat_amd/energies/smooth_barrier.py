@@ -49,8 +49,13 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
     (smooth_barrier.py:34-67).  ``FLAGS`` needs ``smooth_eng_coeff``, ``barrier_coeff`` and
     ``increase_order_iter`` (config/gso.yaml:8-11)."""
 
-    def __init__(self, tet_v, tet_f, FLAGS, **tet_spheres_kwargs) -> None:
+    def __init__(self, tet_v, tet_f, FLAGS, graph: bool = False, **tet_spheres_kwargs) -> None:
         super().__init__()
+        # graph=True (not in the reference): every differentiable evaluation is a HIP-graph replay behind an autograd
+        # node (energies/graphed.py) -- for batches whose 10-30 us of kernels drown in 80 us of per-step host work.
+        # The parameter must keep its storage (in-place optimiser updates, as torch optimisers and AdamUniform do).
+        self.graph = bool(graph)
+        self._graphed = None
         v_flat = np.asarray(tet_v).flatten().astype(np.float32)      # smooth_barrier.py:38
         f_flat = np.asarray(tet_f).flatten().astype(np.int32)        # smooth_barrier.py:39
         self.tet_sp = tet_spheres_ext.TetSpheres(v_flat, f_flat, **tet_spheres_kwargs)
@@ -70,4 +75,10 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
             # logging / validation under torch.no_grad(): energy only -- no fused gradient pass, and a gradient kept for a
             # pending backward() of an earlier evaluation stays where it is
             return tet_spheres_ext.forward(x, self.tet_sp, c1, c2, order, fuse=False)
+        if self.graph and x.requires_grad:
+            from .graphed import GraphedSmoothnessBarrier, GraphReplayFunc
+            gr = self._graphed
+            if gr is None or gr.x.data_ptr() != x.data_ptr() or gr.x.shape != x.shape:
+                gr = self._graphed = GraphedSmoothnessBarrier(self, x.detach())   # (re)capture for this storage
+            return GraphReplayFunc.apply(x, gr, c1, c2, order)
         return SmoothnessBarrierFunc.apply(x, self.tet_sp, c1, c2, order)

@@ -18,7 +18,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy", "slice_replicated"]
+__all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy", "slice_replicated",
+           "WindowedEnergyAllReduce"]
 
 
 def partition_spheres(tets_per_sphere: Sequence[int], world_size: int) -> list[tuple[int, int]]:
@@ -105,6 +106,70 @@ def all_reduce_energy(local_energy: torch.Tensor, group=None, async_op: bool = F
         return (e.reshape(()), None) if async_op else e.reshape(())
     work = dist.all_reduce(e, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return (e.reshape(()), work) if async_op else e.reshape(())
+
+
+class WindowedEnergyAllReduce:
+    """The path's only exchange, batched over steps.
+
+    The gradient of a rank's vertices never depends on the job-wide energy, which a trainer only logs
+    (/root/reference/trainer.py:118-125).  At 8-way strong scaling of the 512-sphere scene a step is ~70 us of
+    kernels, and enqueueing one RCCL all-reduce per step costs the host a comparable amount (measured on one GPU with a
+    single-rank group: profiles/r03_scaling_model.json).  So the local energies of ``window`` consecutive steps go
+    into a ring of device slots -- ``push`` is one 4-byte device copy, no collective -- and every ``window``-th push
+    issues ONE asynchronous all-reduce over the whole window.  ``results()`` returns the reduced energies of every
+    pushed step, in push order (it flushes a partial window and waits for the collectives in flight).
+
+    With one rank or no initialised process group the collective is the identity; everything else runs unchanged.
+    """
+
+    def __init__(self, window: int, device, group=None, max_inflight: int = 2):
+        if window < 1:
+            raise ValueError("window must be >= 1")
+        self.window, self.group, self.max_inflight = int(window), group, max(1, int(max_inflight))
+        self._bufs = [torch.zeros(self.window, dtype=torch.float32, device=device) for _ in range(self.max_inflight + 1)]
+        self._cur, self._fill = 0, 0
+        self._inflight: list[tuple[int, int, object]] = []   # (buffer index, entries, work handle)
+        self._done: list[torch.Tensor] = []
+        self._active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= 1
+        self.collectives = 0
+
+    def push(self, local_energy: torch.Tensor) -> None:
+        self._bufs[self._cur][self._fill:self._fill + 1].copy_(local_energy.detach().reshape(1), non_blocking=True)
+        self._fill += 1
+        if self._fill == self.window:
+            self.flush()
+
+    def _retire(self) -> None:
+        b, cnt, work = self._inflight.pop(0)
+        if work is not None:
+            work.wait()                                   # (stream-side for RCCL: the host does not block)
+        self._done.append(self._bufs[b][:cnt].clone())
+
+    def flush(self) -> None:
+        """All-reduce what the current window holds (also called by ``push`` when a window is full)."""
+        if self._fill == 0:
+            return
+        buf = self._bufs[self._cur]
+        work = None
+        if self._active:
+            work = dist.all_reduce(buf[:self._fill] if self._fill < self.window else buf, op=dist.ReduceOp.SUM,
+                                   group=self.group, async_op=True)
+            self.collectives += 1
+        self._inflight.append((self._cur, self._fill, work))
+        while len(self._inflight) > self.max_inflight:
+            self._retire()
+        busy = {b for b, _, _ in self._inflight}
+        self._cur = next(i for i in range(len(self._bufs)) if i not in busy)
+        self._fill = 0
+
+    def results(self) -> torch.Tensor:
+        """Reduced energies of all steps pushed since the last call (1-D, push order)."""
+        self.flush()
+        while self._inflight:
+            self._retire()
+        out = torch.cat(self._done) if self._done else self._bufs[0][:0].clone()
+        self._done = []
+        return out
 
 
 class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
