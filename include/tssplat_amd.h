@@ -60,14 +60,14 @@ typedef enum tsamd_status {
 typedef struct tsamd_options {
     int32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
-    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU; 54400 with an explicit operator) */
-    int32_t max_threads;       /* workgroup size cap, multiple of 64; 0 = 768 (512 with an explicit operator) */
+    int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU) */
+    int32_t max_threads;       /* workgroup size cap, multiple of 64, <= 768; 0 = 768 */
     int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto            */
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
     int32_t debug_shuffle;     /* experiments: bit0 = spread a tile's tets over lanes, bit1 = no LDS-conflict-aware ordering */
-    int32_t slots_per_thread;  /* tets streamed per lane: 2 (8 B loads, default) or 4 (16 B loads)  */
+    int32_t slots_per_thread;  /* tets streamed per lane: 0 or 2 (the only layout the kernels are built for; 4 is rejected) */
     int32_t rebuild_dminv;     /* 1 = keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
                                 * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per
                                 * evaluation, entries of Dm^-1 within 2.8e-7 relative of the exact inverse instead of

@@ -67,13 +67,11 @@ def test_explicit_uniform_operator_equals_default(ext):
     planes of the two plans are identical."""
     sc = scenes.make_scene("kuhn12", 1)
     L = O.element_laplacian(O.face_adjacency(sc.tets))
-    # (same tiling for both: by default explicit-operator plans use smaller tiles, 512 threads / 54 400 B)
-    ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, max_threads=640, lds_budget_bytes=68000)
-    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L, max_threads=640,
-                          lds_budget_bytes=68000)
+    # (explicit-operator plans use the same tiling as the built-in operator: their extra planes live in registers)
+    ts_d = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True)
+    ts_x = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L)
     assert ts_d.plan_info()["n_planes"] == 13 and ts_x.plan_info()["n_planes"] == 22
-    auto = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, operator=L).plan_info()
-    assert auto["block_threads"] <= 512 and auto["lds_bytes"] <= 54400
+    assert ts_x.plan_info()["block_threads"] == ts_d.plan_info()["block_threads"] and ts_x.plan_info()["lds_bytes"] == ts_d.plan_info()["lds_bytes"]
     for a, b in zip(TE.plan_tiles(ts_d), TE.plan_tiles(ts_x)):
         assert np.array_equal(a["planes"], b["planes"][:13]) and np.array_equal(a["inc"], b["inc"])
     x = scenes.deform(sc, 0.1)
@@ -140,9 +138,7 @@ def test_operator_csr_is_validated(ext):
             ext.TetSpheres(v, t, host_only=True, operator=(rp, ci, bad_va))
     with pytest.raises(RuntimeError, match="not combined with rebuild_dminv"):
         ext.TetSpheres(v, t, host_only=True, operator=csr, rebuild_dminv=True)
-    # explicit-operator kernels are compiled for at most 640 threads; the built-in ones for 768; 4 slots per lane are gone
-    with pytest.raises(RuntimeError, match="max_threads exceeds"):
-        ext.TetSpheres(v, t, host_only=True, operator=csr, max_threads=768)
+    # the tile kernels are compiled for at most 768 threads and two slots per lane
     with pytest.raises(RuntimeError, match="max_threads exceeds"):
         ext.TetSpheres(v, t, host_only=True, max_threads=1024)
     with pytest.raises(RuntimeError, match="slots_per_thread must be 0 or 2"):

@@ -436,8 +436,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
                 for (int c = 0; c < 9; ++c) Fk[p][c] = F[c];
             }
-#ifdef TSAMD_HALO_P1   // experiment: a real branch around det / penalty (halo slots only need F)
-            if (w0 & kOwnedBit) {
+            if (w0 & kOwnedBit) {   // halo slots only contribute F: a real branch (owned / halo is all but wave-uniform in
+                                    // the balanced slot order), tile kernel 0.4643 -> 0.4611 ms (profiles/r03_experiments.md)
                 const float J = det3(F);
                 const float Jm = fmaxf(-J, 0.f);
                 float pen = 0.f, dpen = 0.f;
@@ -451,22 +451,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 e_b += pen;
                 scal[p] = s_pen * dpen;
             }
-#else
-            const float J = det3(F);
-            const float Jm = fmaxf(-J, 0.f);
-            float pen = 0.f, dpen = 0.f;
-            if (a.order == 2) {
-                pen = Jm * Jm;
-                dpen = -2.f * Jm;
-            } else if (a.order == 4) {
-                pen = Jm * Jm * Jm * Jm;
-                dpen = -4.f * Jm * Jm * Jm;
-            }
-            if (w0 & kOwnedBit) {
-                e_b += pen;
-                scal[p] = s_pen * dpen;
-            }
-#endif
             store_slot(smem, t_own[p], F);
             SLOT_FENCE();
         }
@@ -610,17 +594,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
                     q = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
-#ifdef TSAMD_HALO_P3   // experiment: halo slots skip the load of their own (all-zero) H record and the 4 x scaling
-                    if (!(n01 & kOwnedBit)) {
-                        const Mat9 g0 = load_slot(smem, nb[0]), g1 = load_slot(smem, nb[1]), g2 = load_slot(smem, nb[2]),
-                                   g3 = load_slot(smem, nb[3]);
-                        q.p01 = -((g0.p01 + g1.p01) + (g2.p01 + g3.p01));
-                        q.p23 = -((g0.p23 + g1.p23) + (g2.p23 + g3.p23));
-                        q.p45 = -((g0.p45 + g1.p45) + (g2.p45 + g3.p45));
-                        q.p67 = -((g0.p67 + g1.p67) + (g2.p67 + g3.p67));
-                        q.p8 = -((g0.p8 + g1.p8) + (g2.p8 + g3.p8));
-                    } else
-#endif
                     q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb);
                 }
 #ifdef TSAMD_DUMMY_VALU  // experiments: marginal cost of VALU instructions (independent FMAs on four accumulators)
@@ -1067,8 +1040,8 @@ hipError_t configure_kernels(int lds_bytes)
     // without the gradient
     const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreadsWeighted, kWavesWeighted, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreadsWeighted, kWavesWeighted, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6, true>),
+                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6, false, true>),
                          reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6, false, true>)};
     for (const void *fn : fns) {
@@ -1125,11 +1098,11 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         const size_t lds = size_t(e.lds_bytes);
 #endif
         const dim3 grid(unsigned(8 * k.tiles_per_xcd));
-        if (e.block_threads > (e.weighted ? kTileThreadsWeighted : kTileThreads)) return hipErrorInvalidConfiguration;
+        if (e.block_threads > kTileThreads) return hipErrorInvalidConfiguration;
 #define TSAMD_LAUNCH(...) hipLaunchKernelGGL((tile_energy_kernel<__VA_ARGS__>), grid, block, lds, stream, k)
         if (e.weighted) {
-            if (e.grad) TSAMD_LAUNCH(true, kTileThreadsWeighted, kWavesWeighted, true);
-            else TSAMD_LAUNCH(false, kTileThreadsWeighted, kWavesWeighted, true);
+            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6, true);
+            else TSAMD_LAUNCH(false, kTileThreads, 6, true);
         } else if (e.rebuild) {
             if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6, false, true);
             else TSAMD_LAUNCH(false, kTileThreads, 6, false, true);

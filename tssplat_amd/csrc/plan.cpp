@@ -319,19 +319,16 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
     nthreads = std::max(1, std::min(nthreads, 64));
     constexpr int spt = kSlotsPerLane;
-    // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU.  Plans with an explicit operator carry nine more
-    // planes and their kernel needs 92 VGPRs (five waves per SIMD): 512-thread tiles of <= 54 400 B measured fastest
-    // (64 x kuhn19: 0.096 ms against 0.111 ms for 768-thread tiles at one workgroup per CU, 0.119 ms for 640 x 2).
-    const bool small_tiles = op != nullptr && kTileThreadsWeighted < kTileThreads;
-    const int thread_cap = op != nullptr ? kTileThreadsWeighted : kTileThreads;
-    if (opt.max_threads > thread_cap) {
-        err = "max_threads exceeds what the tile kernels are compiled for (" + std::to_string(thread_cap) + ")";
+    // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU -- with or without an explicit operator (its nine
+    // extra planes live in registers, not in LDS, and the kernel still fits 80 VGPRs).
+    if (opt.max_threads > kTileThreads) {
+        err = "max_threads exceeds what the tile kernels are compiled for (" + std::to_string(kTileThreads) + ")";
         return ERR_INVALID;
     }
-    int max_threads = opt.max_threads > 0 ? opt.max_threads : (small_tiles ? 512 : kTileThreads);
+    int max_threads = opt.max_threads > 0 ? opt.max_threads : kTileThreads;
     max_threads = std::max(64, (max_threads / 64) * 64);
     Limits lim;
-    lim.budget = opt.lds_budget > 0 ? opt.lds_budget : (small_tiles ? 54400 : 80 * 1024);
+    lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 80 * 1024;
     lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 2728);  // record tokens (12 idx + rot) are 15-bit fields
     lim.rebuild = opt.rebuild_dminv != 0 && op == nullptr;
     if (lim.budget < tile_lds_bytes(8, 8, lim.rebuild)) {

@@ -25,8 +25,8 @@ struct PlanOptions {
     // Defaults = the measured optimum on MI355X (profiles/README.md): two 768-thread workgroups per
     // CU, 2 tets per lane, 80 KiB of LDS each -- 24 waves per CU hide the LDS-gather latency that one
     // 1024-thread / 160 KiB workgroup (4 tets per lane) leaves exposed.
-    int lds_budget = 0;           // bytes of LDS one workgroup may use; 0 = 80 KiB (54 400 B with an explicit operator)
-    int max_threads = 0;          // workgroup size cap (multiple of 64, <= kTileThreads / kTileThreadsWeighted); 0 = 768 (512 with an explicit operator)
+    int lds_budget = 0;           // bytes of LDS one workgroup may use; 0 = 80 KiB
+    int max_threads = 0;          // workgroup size cap (multiple of 64, <= kTileThreads); 0 = 768
     int target_owned = 0;         // 0 = auto
     int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
@@ -58,17 +58,11 @@ static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI
 //   n_verts + 1 x u16         : first chunk of every local vertex
 constexpr int kPlanes = 13;
 // Lane layout the kernels are compiled for: two consecutive slots per lane (one 8-byte load per plane), workgroups of
-// at most 768 threads (80-VGPR build: two workgroups per CU when a tile's LDS is <= 80 KiB); explicit-operator plans
-// use at most 640 (92 VGPRs, five waves per SIMD).
+// at most 768 threads (80-VGPR builds, also with an explicit operator: 78 VGPRs, no spill): two workgroups per CU
+// when a tile's LDS is <= 80 KiB.  (Round 2 ran explicit-operator plans on 512-thread / 54 400 B tiles with a
+// 92-VGPR kernel: 0.0942 ms on 64 x kuhn19 against 0.0836 ms for this layout, built-in operator 0.0593 ms.)
 constexpr int kSlotsPerLane = 2;
 constexpr int kTileThreads = 768;
-#ifdef TSAMD_W768   // experiment: explicit-operator kernels at the built-in kernels' launch bounds (78 VGPRs, no spill)
-constexpr int kTileThreadsWeighted = 768;
-constexpr int kWavesWeighted = 6;
-#else
-constexpr int kTileThreadsWeighted = 640;
-constexpr int kWavesWeighted = 5;
-#endif
 // Plans built with an explicit element operator (build_plan's `op`) carry 9 more fp32 planes per slot:
 //   [13]      L[e, e]
 //   [14..17]  L[e, n_k]   row weights, in the slot's (possibly re-ordered) neighbour order -- pass 2, H = L F
