@@ -170,6 +170,22 @@ int tsamd_forward_backward(tsamd_handle *h, const float *x_dev, const float *gra
  */
 int tsamd_evaluate_dev_coef(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, const float *coef_dev,
                             int order, void *stream, float *energy_dev, float *grad_dev);
+/*
+ * The fused evaluation as an instantiated HIP graph (tile kernel -> finish kernel), for batches whose 10-30 us of kernels
+ * drown in per-step host work (the reference pays ~80 us of launches, descriptor set-up and three blocking device reads
+ * per iteration at trainer.py:94,130).  tsamd_graph_create bakes in the pointers (x_dev, grad_out_dev -- may be NULL --,
+ * energy_dev, grad_dev; at least one of the two outputs) and `order`; tsamd_graph_launch replays it on `stream` with the
+ * coefficients of THIS iteration -- they are kernel arguments of the graph's nodes and are updated on the host
+ * (hipGraphExecKernelNodeSetParams), so following the reference's schedule (energies/smooth_barrier.py:47-58) costs
+ * nothing on the device.  Same kernels, same results as tsamd_forward_backward.  The graph borrows the handle's scratch:
+ * the single-stream rule of the handle applies, and the handle must outlive the graph.
+ */
+typedef struct tsamd_graph tsamd_graph;
+int tsamd_graph_create(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, int order, float *energy_dev,
+                       float *grad_dev, tsamd_graph **out);
+int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream);
+void tsamd_graph_destroy(tsamd_graph *graph);
+
 /* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 

@@ -1,6 +1,6 @@
 /* Plain-C consumer of the DEVICE entry points of include/tssplat_amd.h: a compiled C99 program (no Python, no torch,
  * no ctypes) creates a handle on the GPU, evaluates energy + gradient through tsamd_forward_backward,
- * tsamd_forward, tsamd_backward and tsamd_evaluate_dev_coef, and checks them against the float64 C oracle
+ * tsamd_forward, tsamd_backward, tsamd_evaluate_dev_coef and tsamd_graph_create / tsamd_graph_launch, and checks them against the float64 C oracle
  * (oracle/c/tet_energy_oracle.c, test infrastructure) on a small lattice of tets.
  * Built and run by tests/test_gpu_parity.py::test_compiled_c_consumer_on_device:
  *   gcc -std=c99 abi_device.c -ltssplat_amd -ltet_energy_oracle -lamdhip64 */
@@ -100,14 +100,21 @@ int main(void)
         for (i = 0; i < 3 * NV; ++i) gn += g_ref[i] * g_ref[i];
         gn = sqrt(gn);
         if (E_ref[2] <= 0.0) return 13; /* the case is meant to exercise the inversion penalty */
-        for (variant = 0; variant < 3; ++variant) {
+        for (variant = 0; variant < 4; ++variant) {
             HIPCHK(hipMemset(d_g, 0xff, sizeof g_gpu));
             if (variant == 0)
                 rc = tsamd_forward_backward(h, d_x, d_go, c1, c2, order, NULL, d_e, d_g);
             else if (variant == 1)
                 rc = tsamd_evaluate_dev_coef(h, d_x, d_go, d_coef, order, NULL, d_e, d_g);
-            else
+            else if (variant == 2)
                 rc = tsamd_forward(h, d_x, c1, c2, order, NULL, d_e) || tsamd_backward(h, d_x, d_go, c1, c2, order, NULL, d_g);
+            else { /* the library-owned HIP graph: first launch with other coefficients, then with the real ones */
+                tsamd_graph *gr = NULL;
+                rc = tsamd_graph_create(h, d_x, d_go, order, d_e, d_g, &gr) || tsamd_graph_launch(gr, 3.f * c1, 0.5f * c2, NULL) ||
+                     tsamd_graph_launch(gr, c1, c2, NULL);
+                HIPCHK(hipDeviceSynchronize());
+                tsamd_graph_destroy(gr);
+            }
             if (rc != TSAMD_OK) {
                 fprintf(stderr, "evaluate (variant %d): %s\n", variant, tsamd_last_error());
                 return 14;

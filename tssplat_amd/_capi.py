@@ -84,6 +84,9 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsamd_evaluate_dev_coef": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    "tsamd_graph_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tsamd_graph_launch": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
+    "tsamd_graph_destroy": (None, [C.c_void_p]),
     "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "tsamd_debug_set_ablation": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_debug_read_clocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -61,6 +61,11 @@ struct tsamd_handle {
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
 
+struct tsamd_graph {
+    tsamd::EvalGraph *g = nullptr;
+    int device = -1;
+};
+
 namespace {
 
 template <class T>
@@ -195,13 +200,9 @@ int check_eval(tsamd_handle *h, const float *x)
     return TSAMD_OK;
 }
 
-int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, float c2, int order, void *stream,
-             float *energy, float *grad, const float *coef = nullptr)
+tsamd::EvalArgs eval_args(tsamd_handle *h, const float *x, const float *grad_out, float c1, float c2, int order, float *energy,
+                          float *grad, const float *coef)
 {
-    int rc = check_eval(h, x);
-    if (rc) return rc;
-    DeviceGuard g;
-    TSAMD_HIP(g.enter(h->device));
     tsamd::EvalArgs a;
     a.tiles = h->d_tiles;
     a.blob = h->d_blob;
@@ -228,6 +229,17 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
     a.partials = h->d_partials;
     a.energy = energy;
     a.terms = h->d_terms;
+    return a;
+}
+
+int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, float c2, int order, void *stream,
+             float *energy, float *grad, const float *coef = nullptr)
+{
+    int rc = check_eval(h, x);
+    if (rc) return rc;
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    const tsamd::EvalArgs a = eval_args(h, x, grad_out, c1, c2, order, energy, grad, coef);
     if (h->timing) {
         hipEvent_t ev[3];
         for (auto &e : ev) TSAMD_HIP(hipEventCreate(&e));
@@ -372,6 +384,49 @@ int tsamd_evaluate_dev_coef(tsamd_handle *h, const float *x_dev, const float *gr
     if (!energy_dev && !grad_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "nothing to compute: energy_dev and grad_dev are both null");
     return evaluate(h, x_dev, grad_out_dev, 0.f, 0.f, order, stream,
                     energy_dev ? energy_dev : (grad_dev && h ? h->d_energy_scratch : nullptr), grad_dev, coef_dev);
+}
+
+int tsamd_graph_create(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, int order, float *energy_dev,
+                       float *grad_dev, tsamd_graph **out)
+{
+    if (!out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int rc = check_eval(h, x_dev);
+    if (rc) return rc;
+    if (!energy_dev && !grad_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "nothing to compute: energy_dev and grad_dev are both null");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    const tsamd::EvalArgs a = eval_args(h, x_dev, grad_out_dev, 0.f, 0.f, order,
+                                        energy_dev ? energy_dev : h->d_energy_scratch, grad_dev, nullptr);
+    tsamd::EvalGraph *eg = nullptr;
+    TSAMD_HIP(tsamd::eval_graph_create(a, &eg));
+    tsamd_graph *w = new (std::nothrow) tsamd_graph();
+    if (!w) {
+        tsamd::eval_graph_destroy(eg);
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
+    }
+    w->g = eg;
+    w->device = h->device;
+    *out = w;
+    return TSAMD_OK;
+}
+
+int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream)
+{
+    if (!graph || !graph->g) return fail(TSAMD_ERR_INVALID_ARGUMENT, "graph is null");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(graph->device));
+    TSAMD_HIP(tsamd::eval_graph_launch(graph->g, c1, c2, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+void tsamd_graph_destroy(tsamd_graph *graph)
+{
+    if (!graph) return;
+    DeviceGuard g;
+    (void)g.enter(graph->device);
+    tsamd::eval_graph_destroy(graph->g);
+    delete graph;
 }
 
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)

@@ -36,6 +36,12 @@ struct EvalArgs {
 
 // ev: optional 3 events recorded before the tile kernel, between the two kernels, after the finish kernel
 hipError_t launch_eval(const EvalArgs &a, hipStream_t stream, hipEvent_t *ev = nullptr);
+// The same evaluation as an instantiated HIP graph whose coefficients are updated per launch as kernel-node arguments.
+// The EvalArgs pointers (x, grad_out, energy, grad, plan data) are baked in; e.coef must be null.
+struct EvalGraph;
+hipError_t eval_graph_create(const EvalArgs &a, EvalGraph **out);
+hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream);
+void eval_graph_destroy(EvalGraph *g);
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
 hipError_t launch_adam_uniform(float *p, const float *grad, float *g1, float *g2, int64_t n, float lr, float b1, float b2,

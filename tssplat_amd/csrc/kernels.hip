@@ -1070,10 +1070,23 @@ hipError_t launch_eval(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev)
     return rc;
 }
 
-hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev)
+namespace {
+
+// What one evaluation launches: the tile kernel (if the plan has tiles) and then either the finish kernel (shared-vertex
+// sums + the energy reduction in its workgroup 0) or, without a gradient, the energy reduction alone.  One description
+// serves the stream launches below and the nodes of an EvalGraph.
+struct LaunchRecipe {
+    KernelArgs k;
+    FinishArgs f;
+    const void *tile_fn = nullptr, *finish_fn = nullptr;   // nullptr = not launched
+    dim3 tile_grid, tile_block, finish_grid, finish_block;
+    size_t tile_lds = 0;
+};
+
+hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
 {
     if (e.n_tiles > 0) {
-        KernelArgs k;
+        KernelArgs &k = r.k;
         k.tiles = e.tiles;
         k.blob = e.blob;
         k.gvid = e.gvid;
@@ -1091,34 +1104,24 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.dbg = e.dbg;
         k.clk = e.clk;
-        const dim3 block(unsigned(e.block_threads));
-#ifdef TSAMD_ABLATION
-        const size_t lds = ablation_lds_request(size_t(e.lds_bytes));
-#else
-        const size_t lds = size_t(e.lds_bytes);
-#endif
-        const dim3 grid(unsigned(8 * k.tiles_per_xcd));
         if (e.block_threads > kTileThreads) return hipErrorInvalidConfiguration;
-#define TSAMD_LAUNCH(...) hipLaunchKernelGGL((tile_energy_kernel<__VA_ARGS__>), grid, block, lds, stream, k)
-        if (e.weighted) {
-            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6, true);
-            else TSAMD_LAUNCH(false, kTileThreads, 6, true);
-        } else if (e.rebuild) {
-            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6, false, true);
-            else TSAMD_LAUNCH(false, kTileThreads, 6, false, true);
-        } else {
-            if (e.grad) TSAMD_LAUNCH(true, kTileThreads, 6);
-            else TSAMD_LAUNCH(false, kTileThreads, 6);
-        }
-#undef TSAMD_LAUNCH
-        hipError_t err = hipGetLastError();
-        if (err != hipSuccess) return err;
+        r.tile_block = dim3(unsigned(e.block_threads));
+        r.tile_grid = dim3(unsigned(8 * k.tiles_per_xcd));
+#ifdef TSAMD_ABLATION
+        r.tile_lds = ablation_lds_request(size_t(e.lds_bytes));
+#else
+        r.tile_lds = size_t(e.lds_bytes);
+#endif
+#define TSAMD_FN(...) reinterpret_cast<const void *>(&tile_energy_kernel<__VA_ARGS__>)
+        if (e.weighted)
+            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6, true) : TSAMD_FN(false, kTileThreads, 6, true);
+        else if (e.rebuild)
+            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6, false, true) : TSAMD_FN(false, kTileThreads, 6, false, true);
+        else
+            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6) : TSAMD_FN(false, kTileThreads, 6);
+#undef TSAMD_FN
     }
-    if (ev) {
-        hipError_t err = hipEventRecord(ev[1], stream);
-        if (err != hipSuccess) return err;
-    }
-    FinishArgs f;
+    FinishArgs &f = r.f;
     f.fin_vid = e.fin_vid;
     f.fin_off = e.fin_off;
     f.fin_idx = e.fin_idx;
@@ -1135,14 +1138,115 @@ hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t
     f.terms = e.terms;
     if (f.n_finish > 0) {
         // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
-        hipLaunchKernelGGL(finish_kernel, dim3(1u + unsigned(grid_for(f.n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
-        return hipGetLastError();
-    }
-    if (f.energy) {
-        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
-        return hipGetLastError();
+        r.finish_fn = reinterpret_cast<const void *>(&finish_kernel);
+        r.finish_grid = dim3(1u + unsigned(grid_for(f.n_finish, 256, 1 << 20)));
+        r.finish_block = dim3(256);
+    } else if (f.energy) {
+        r.finish_fn = reinterpret_cast<const void *>(&energy_reduce_kernel);
+        r.finish_grid = dim3(1);
+        r.finish_block = dim3(1024);
     }
     return hipSuccess;
+}
+
+}  // namespace
+
+hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev)
+{
+    LaunchRecipe r;
+    hipError_t err = make_recipe(e, r);
+    if (err != hipSuccess) return err;
+    if (r.tile_fn) {
+        void *argv[] = {&r.k};
+        err = hipLaunchKernel(r.tile_fn, r.tile_grid, r.tile_block, argv, r.tile_lds, stream);
+        if (err != hipSuccess) return err;
+    }
+    if (ev) {
+        err = hipEventRecord(ev[1], stream);
+        if (err != hipSuccess) return err;
+    }
+    if (r.finish_fn) {
+        void *argv[] = {&r.f};
+        err = hipLaunchKernel(r.finish_fn, r.finish_grid, r.finish_block, argv, 0, stream);
+        if (err != hipSuccess) return err;
+    }
+    return hipSuccess;
+}
+
+// ---- the evaluation as an explicit HIP graph (tile node -> finish node) ----
+// The coefficients are kernel ARGUMENTS of both nodes: a launch updates them with hipGraphExecKernelNodeSetParams --
+// host-side bookkeeping, nothing on the GPU's timeline -- so a replay follows the reference's coefficient schedule
+// (energies/smooth_barrier.py:47-58) without a device-side coefficient buffer and its per-step 8-byte copy (measured
+// round 3: 64 x kuhn8 24.3 us per replayed step with that copy against 15.6 us with constant coefficients).
+struct EvalGraph {
+    LaunchRecipe r;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t tile_node = nullptr, finish_node = nullptr;
+    hipKernelNodeParams tile_p, finish_p;
+    void *tile_argv[1], *finish_argv[1];
+};
+
+hipError_t eval_graph_create(const EvalArgs &e, EvalGraph **out)
+{
+    *out = nullptr;
+    EvalGraph *g = new EvalGraph();
+    hipError_t err = make_recipe(e, g->r);
+    auto fail = [&](hipError_t code) {
+        eval_graph_destroy(g);
+        return code;
+    };
+    if (err != hipSuccess) return fail(err);
+    if ((err = hipGraphCreate(&g->graph, 0)) != hipSuccess) return fail(err);
+    if (g->r.tile_fn) {
+        g->tile_argv[0] = &g->r.k;
+        hipKernelNodeParams &p = g->tile_p;
+        p = hipKernelNodeParams{};
+        p.func = const_cast<void *>(g->r.tile_fn);
+        p.gridDim = g->r.tile_grid;
+        p.blockDim = g->r.tile_block;
+        p.sharedMemBytes = unsigned(g->r.tile_lds);
+        p.kernelParams = g->tile_argv;
+        p.extra = nullptr;
+        if ((err = hipGraphAddKernelNode(&g->tile_node, g->graph, nullptr, 0, &p)) != hipSuccess) return fail(err);
+    }
+    if (g->r.finish_fn) {
+        g->finish_argv[0] = &g->r.f;
+        hipKernelNodeParams &p = g->finish_p;
+        p = hipKernelNodeParams{};
+        p.func = const_cast<void *>(g->r.finish_fn);
+        p.gridDim = g->r.finish_grid;
+        p.blockDim = g->r.finish_block;
+        p.sharedMemBytes = 0;
+        p.kernelParams = g->finish_argv;
+        p.extra = nullptr;
+        if ((err = hipGraphAddKernelNode(&g->finish_node, g->graph, g->tile_node ? &g->tile_node : nullptr, g->tile_node ? 1 : 0, &p)) !=
+            hipSuccess)
+            return fail(err);
+    }
+    if ((err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)) != hipSuccess) return fail(err);
+    *out = g;
+    return hipSuccess;
+}
+
+hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream)
+{
+    hipError_t err;
+    if (g->r.k.c1 != c1 || g->r.k.c2 != c2 || g->r.f.c1 != c1 || g->r.f.c2 != c2) {
+        g->r.k.c1 = g->r.f.c1 = c1;
+        g->r.k.c2 = g->r.f.c2 = c2;
+        if (g->tile_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile_node, &g->tile_p)) != hipSuccess) return err;
+        if (g->finish_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish_node, &g->finish_p)) != hipSuccess) return err;
+    }
+    return hipGraphLaunch(g->exec, stream);
+}
+
+void eval_graph_destroy(EvalGraph *g)
+{
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
 }
 
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream)

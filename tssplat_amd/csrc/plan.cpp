@@ -23,10 +23,24 @@
 #include <limits>
 #include <numeric>
 #include <sstream>
+#include <chrono>
 #include <thread>
 
 namespace tsamd {
 namespace {
+
+// TSAMD_PLAN_TIMING=1 prints the wall time of every stage of build_plan to stderr (tuning aid)
+struct StageTimer {
+    bool on = std::getenv("TSAMD_PLAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[plan] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 enum { OK = 0, ERR_INVALID = 1, ERR_BAD_MESH = 2, ERR_IO = 5, ERR_TILING = 6 };
 
@@ -73,28 +87,39 @@ int build_adjacency(const int32_t *tets, int64_t n, int64_t m, std::vector<int32
 {
     static const int opp[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
     nbr.assign(size_t(4 * m), -1);
-    std::vector<int64_t> start(size_t(n + 1), 0);
-    for (int64_t e = 0; e < m; ++e) {
-        const int32_t *t = tets + 4 * e;
-        for (int k = 0; k < 4; ++k) {
-            uint32_t a = t[opp[k][0]], b = t[opp[k][1]], c = t[opp[k][2]];
-            sort3(a, b, c);
-            ++start[a + 1];
-        }
-    }
-    for (int64_t v = 0; v < n; ++v) start[v + 1] += start[v];
-    std::vector<BucketFace> faces(size_t(4 * m));
-    {
-        std::vector<int64_t> cur(start.begin(), start.end() - 1);
-        for (int64_t e = 0; e < m; ++e) {
+    // bucket the 4 m faces by their smallest vertex: count, prefix sum, fill -- counting and filling in parallel with
+    // atomic per-bucket cursors (the order inside a bucket is arbitrary here; every bucket is sorted below)
+    std::vector<std::atomic<int32_t>> count(static_cast<size_t>(n));
+    parallel_chunks(n, 1 << 16, nthreads, [&](int64_t b, int64_t e, int) {
+        for (int64_t v = b; v < e; ++v) count[size_t(v)].store(0, std::memory_order_relaxed);
+    });
+    parallel_chunks(m, 1 << 15, nthreads, [&](int64_t eb, int64_t ee, int) {
+        for (int64_t e = eb; e < ee; ++e) {
             const int32_t *t = tets + 4 * e;
             for (int k = 0; k < 4; ++k) {
                 uint32_t a = t[opp[k][0]], b = t[opp[k][1]], c = t[opp[k][2]];
                 sort3(a, b, c);
-                faces[size_t(cur[a]++)] = BucketFace{b, c, uint32_t(4 * e + k)};
+                count[a].fetch_add(1, std::memory_order_relaxed);
             }
         }
-    }
+    });
+    std::vector<int64_t> start(size_t(n + 1), 0);
+    for (int64_t v = 0; v < n; ++v) start[v + 1] = start[v] + count[size_t(v)].load(std::memory_order_relaxed);
+    RawVector<BucketFace> faces(size_t(4 * m));
+    parallel_chunks(n, 1 << 16, nthreads, [&](int64_t b, int64_t e, int) {
+        for (int64_t v = b; v < e; ++v) count[size_t(v)].store(0, std::memory_order_relaxed);
+    });
+    parallel_chunks(m, 1 << 15, nthreads, [&](int64_t eb, int64_t ee, int) {
+        for (int64_t e = eb; e < ee; ++e) {
+            const int32_t *t = tets + 4 * e;
+            for (int k = 0; k < 4; ++k) {
+                uint32_t a = t[opp[k][0]], b = t[opp[k][1]], c = t[opp[k][2]];
+                sort3(a, b, c);
+                const int64_t pos = start[a] + count[a].fetch_add(1, std::memory_order_relaxed);
+                faces[size_t(pos)] = BucketFace{b, c, uint32_t(4 * e + k)};
+            }
+        }
+    });
     std::atomic<int> bad{0};
     parallel_chunks(n, 4096, nthreads, [&](int64_t vb, int64_t ve, int) {
         for (int64_t v = vb; v < ve; ++v) {
@@ -303,6 +328,7 @@ struct Splitter {
 int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, const PlanOptions &opt, Plan &P,
                std::string &err, const ElementOperatorCSR *op)
 {
+    StageTimer timer;
     if (n < 0 || m < 0 || (n > 0 && !rest) || (m > 0 && !tets)) {
         err = "null pointer or negative size";
         return ERR_INVALID;
@@ -316,6 +342,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             err = "tet index out of range at flat position " + std::to_string(i);
             return ERR_INVALID;
         }
+    timer.lap("index check");
     int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
     nthreads = std::max(1, std::min(nthreads, 64));
     constexpr int spt = kSlotsPerLane;
@@ -343,6 +370,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     int rc = build_adjacency(tets, n, m, P.nbr, nthreads, err);
     if (rc) return rc;
     Mesh M{rest, tets, P.nbr.data(), n, m};
+    timer.lap("face adjacency");
 
     // ---- explicit element operator: CSR -> (diagonal, one weight per tet face) ----
     if (op) {
@@ -402,36 +430,65 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     const int n_planes = P.n_planes;
 
     // ---- connected components over face adjacency (each tet-sphere is one) ----
+    // Lock-free union-find over the face adjacency: the larger root is always linked under the smaller one, so a
+    // component's root is its smallest tet id whatever the thread interleaving -- components are then numbered by that
+    // id and list their tets in increasing order, exactly what the serial flood fill of rounds 1-2 produced.
     std::vector<int32_t> comp(size_t(m), -1);
     std::vector<int64_t> comp_start;
-    std::vector<int32_t> comp_tets(static_cast<size_t>(m));
+    RawVector<int32_t> comp_tets(static_cast<size_t>(m));
     {
-        int64_t filled = 0;
-        std::vector<int32_t> stack;
-        for (int64_t s = 0; s < m; ++s) {
-            if (comp[size_t(s)] >= 0) continue;
-            const int32_t c = int32_t(comp_start.size());
-            comp_start.push_back(filled);
-            comp[size_t(s)] = c;
-            stack.push_back(int32_t(s));
-            const int64_t first = filled;
-            while (!stack.empty()) {
-                int32_t e = stack.back();
-                stack.pop_back();
-                comp_tets[size_t(filled++)] = e;
+        std::vector<std::atomic<int32_t>> parent(static_cast<size_t>(m));
+        parallel_chunks(m, 1 << 16, nthreads, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i) parent[size_t(i)].store(int32_t(i), std::memory_order_relaxed);
+        });
+        auto find = [&](int32_t x) {
+            for (;;) {
+                const int32_t p = parent[size_t(x)].load(std::memory_order_relaxed);
+                if (p == x) return x;
+                const int32_t gp = parent[size_t(p)].load(std::memory_order_relaxed);
+                if (gp != p) {   // path halving (a lost race only skips the shortcut)
+                    int32_t expect = p;
+                    parent[size_t(x)].compare_exchange_weak(expect, gp, std::memory_order_relaxed);
+                }
+                x = p;
+            }
+        };
+        parallel_chunks(m, 1 << 15, nthreads, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i)
                 for (int k = 0; k < 4; ++k) {
-                    int32_t q = P.nbr[4 * size_t(e) + k];
-                    if (q >= 0 && comp[size_t(q)] < 0) {
-                        comp[size_t(q)] = c;
-                        stack.push_back(q);
+                    const int32_t q = P.nbr[4 * size_t(i) + k];
+                    if (q < 0 || q > i) continue;            // every interior face once, from its larger tet
+                    int32_t ra = find(int32_t(i)), rb = find(q);
+                    while (ra != rb) {
+                        int32_t hi = std::max(ra, rb), lo = std::min(ra, rb);
+                        int32_t expect = hi;
+                        if (parent[size_t(hi)].compare_exchange_strong(expect, lo, std::memory_order_relaxed)) break;
+                        ra = find(hi);
+                        rb = find(lo);
                     }
                 }
-            }
-            std::sort(comp_tets.begin() + first, comp_tets.begin() + filled);
+        });
+        // roots in increasing order = component numbers; tets of a component in increasing order (counting sort)
+        std::vector<int32_t> root_comp(static_cast<size_t>(m), -1);
+        RawVector<int32_t> root_of(static_cast<size_t>(m));
+        parallel_chunks(m, 1 << 15, nthreads, [&](int64_t b, int64_t e, int) {
+            for (int64_t i = b; i < e; ++i) root_of[size_t(i)] = find(int32_t(i));
+        });
+        int64_t ncomp = 0;
+        for (int64_t i = 0; i < m; ++i)
+            if (root_of[size_t(i)] == i) root_comp[size_t(i)] = int32_t(ncomp++);
+        std::vector<int64_t> fill(static_cast<size_t>(ncomp) + 1, 0);
+        for (int64_t i = 0; i < m; ++i) {
+            const int32_t c = root_comp[size_t(root_of[size_t(i)])];
+            comp[size_t(i)] = c;
+            ++fill[size_t(c) + 1];
         }
-        comp_start.push_back(filled);
+        for (int64_t c = 0; c < ncomp; ++c) fill[size_t(c) + 1] += fill[size_t(c)];
+        comp_start.assign(fill.begin(), fill.end());
+        for (int64_t i = 0; i < m; ++i) comp_tets[size_t(fill[size_t(comp[size_t(i)])]++)] = int32_t(i);
     }
     const int64_t C = int64_t(comp_start.size()) - 1;
+    timer.lap("components");
     P.n_components = C;
 
     // ---- tet centroids (rest state) ----
@@ -465,6 +522,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     });
 
+    timer.lap("centroids + fit check");
     // ---- group: pack small components together, bisect large ones ----
     // group g covers components [gb, ge); a group of one non-fitting component is bisected.
     struct Group {
@@ -544,6 +602,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         return first_rc.load();
     }
 
+    timer.lap("bisection");
     std::vector<std::vector<int32_t>> tiles_owned;
     for (auto &gt : group_tiles)
         for (auto &t : gt) tiles_owned.push_back(std::move(t));
@@ -594,6 +653,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     });
 
+    timer.lap("pass A (halo, vertex lists)");
     // ---- tile vertex order: exclusive vertices first, then the shared ones; inside each class longest
     // incidence list first, so that the lanes of a wave of the per-vertex gather carry lists of about the
     // same length (a wave runs as long as its longest list) ----
@@ -613,6 +673,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     });
 
+    timer.lap("vertex order");
     // ---- offsets ----
     P.tiles.resize(size_t(T));
     P.slot_base.resize(size_t(T) + 1);
@@ -658,10 +719,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     P.total_tile_verts = vert_off;
     P.n_stage = stage_off;
     P.block_threads = std::min(max_threads, ((max_quads + 63) / 64) * 64);
-    P.blob.assign(size_t(blob_bytes / 4), 0u);
+    P.blob.resize(size_t(blob_bytes / 4));   // (uninitialised: every tile zero-fills its own range in pass B)
     P.gvid.resize(size_t(vert_off));
-    P.slot_tet.assign(size_t(slot_off), -1);
+    P.slot_tet.resize(size_t(slot_off));
 
+    timer.lap("offsets + allocation");
     // ---- pass B: fill planes ----
     std::atomic<int> singular{0};
     const bool balance = opt.balance != 0;
@@ -697,6 +759,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 S.tet_slot[el] = slot_of_item(L);
             }
             uint32_t *pl = P.blob.data() + d.blob_off / 4;
+            {   // this tile's part of the (uninitialised) plan arrays
+                const uint64_t blob_end = t + 1 < T ? P.tiles[size_t(t) + 1].blob_off : uint64_t(P.blob.size()) * 4;
+                std::memset(pl, 0, size_t(blob_end - d.blob_off));
+                std::fill_n(P.slot_tet.data() + P.slot_base[size_t(t)], size_t(d.s_pad), int32_t(-1));
+            }
             const uint32_t ZS = uint32_t(d.s_pad);
             // padding slots: lv = 0, neighbours = the slot itself, dminv = 0 (F = 0, forces = 0, no incidence entries)
             for (int32_t s = 0; s < d.s_pad; ++s) {
@@ -993,6 +1060,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             }
         }
     });
+    timer.lap("pass B (planes, colouring, incidence matching)");
     if (singular.load()) {
         err = "singular (zero-volume) rest tetrahedron";
         return ERR_BAD_MESH;
@@ -1029,6 +1097,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             }
         }
     }
+    timer.lap("finish lists");
     return OK;
 }
 

@@ -1,22 +1,25 @@
 """HIP-graph replay of the energy forward+backward for launch-bound batches.
 
 For the reference's own problem sizes (64-256 tet-spheres of ~3 k tets, BASELINE.json configs 2-3) one
-evaluation is 10-30 us of kernels, while the eager route through ``torch.autograd`` costs 50-70 us of host
+evaluation is 10-30 us of kernels, while the eager route through ``torch.autograd`` costs 70-80 us of host
 time per step (tools/host_overhead.py) -- the reference pays that, plus three blocking device reads, at
-/root/reference/trainer.py:94,130 in every iteration.  ``GraphedSmoothnessBarrier`` captures the fused
-evaluation once (the tile and finish kernels) and replays it; the schedule of
-``SmoothnessBarrierEnergy.coeff_scheduler`` (smooth_barrier.py:47-58) keeps working because the kernels read ``c1, c2`` from device memory (``tsamd_evaluate_dev_coef``), refreshed by one small asynchronous
-copy in front of the replay whenever they change (never while they are constant).  The order switch 2 -> 4
-(smooth_barrier.py:61-63) selects a second graph, captured on first use.
+/root/reference/trainer.py:94,130 in every iteration.  ``GraphedSmoothnessBarrier`` replays the fused evaluation
+(the tile and finish kernels) from a HIP graph that the library builds once per order (``tsamd_graph_create``); the
+schedule of ``SmoothnessBarrierEnergy.coeff_scheduler`` (smooth_barrier.py:47-58) keeps working because the
+coefficients are kernel arguments of the graph's nodes, updated on the host at every launch.  The order switch 2 -> 4
+(smooth_barrier.py:61-63) selects a second graph, built on first use.
 
 The result is the same energy and the same gradient as ``SmoothnessBarrierEnergy`` + ``backward()`` with
 ``grad_output = grad_scale``; it is written to ``self.energy`` / ``self.grad`` (static buffers, overwritten by
 every ``step``).  ``step`` itself does not go through autograd: add ``self.grad`` to the parameter's ``.grad`` (or
 hand it to ``AdamUniform``) yourself.  For code shaped like the reference trainer (``loss = ... + energy(x, it, c1, c2)``,
 ``loss.backward()``, /root/reference/trainer.py:94-130) ``SmoothnessBarrierEnergy(..., graph=True)`` wraps the same
-replay in an autograd node (``GraphReplayFunc``): the trainer keeps its shape and gets the replayed kernels.
+replay in an autograd node (``GraphReplayFunc``): the trainer keeps its shape and gets the replayed kernels -- though
+on this path the ~70 us that ``torch.autograd`` itself spends on a custom Function round trip dominate the step.
 """
 from __future__ import annotations
+
+import ctypes as C
 
 import torch
 
@@ -35,6 +38,10 @@ class GraphedSmoothnessBarrier:
     ``increase_order_iter``); ``x`` -- the ``[n, 3]`` float32 parameter on the GPU; ``grad_scale`` -- the factor
     the reference applies as ``grad_output`` (tet_spheres_cuda.cu:257-258), e.g. the weight of the
     regularisation term in the loss.
+
+    The graph lives in the library (``tsamd_graph_create`` / ``tsamd_graph_launch``): two kernel nodes whose coefficient
+    arguments are updated on the host at every launch, so the reference's schedule (coefficients change every iteration
+    up to it = 1200, smooth_barrier.py:47-58) costs nothing on the device.
     """
 
     def __init__(self, energy: SmoothnessBarrierEnergy, x: torch.Tensor, grad_scale: float = 1.0):
@@ -48,54 +55,34 @@ class GraphedSmoothnessBarrier:
         dev = x.device
         self.energy = torch.zeros((), dtype=torch.float32, device=dev)
         self.grad = torch.zeros_like(x.detach())
-        self._coef = torch.zeros(2, dtype=torch.float32, device=dev)
-        # pinned staging ring for the coefficients: a slot is rewritten only after the copy that read it has run
-        self._ring = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(8)]
-        self._ring_ev = [None] * len(self._ring)
-        self._ring_pos = 0
-        self._last = None
         self._scale = torch.full((1,), float(grad_scale), dtype=torch.float32, device=dev)
-        self._graphs: dict[int, torch.cuda.CUDAGraph] = {}
-        self._stream = torch.cuda.Stream(device=dev)
+        self._graphs: dict[int, C.c_void_p] = {}
         self.ticket = 0            # evaluations so far (GraphReplayFunc: a backward must belong to the latest one)
 
-    def _launch(self, order: int) -> None:
-        stream = tet_spheres_ext._stream_ptr(self.x.device)
-        _capi.check(_lib.tsamd_evaluate_dev_coef(self.module.tet_sp._handle(), self.x.data_ptr(), self._scale.data_ptr(),
-                                                 self._coef.data_ptr(), int(order), stream, self.energy.data_ptr(),
-                                                 self.grad.data_ptr()))
-
-    def _capture(self, order: int) -> torch.cuda.CUDAGraph:
-        dev = self.x.device
-        with torch.cuda.device(dev):
-            self._stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(self._stream):        # warm-up outside capture (first-launch module loading)
-                self._launch(order)
-            torch.cuda.current_stream(dev).wait_stream(self._stream)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._stream):
-                self._launch(order)
+    def _create(self, order: int) -> C.c_void_p:
+        g = C.c_void_p()
+        _capi.check(_lib.tsamd_graph_create(self.module.tet_sp._handle(), self.x.data_ptr(), self._scale.data_ptr(), int(order),
+                                            self.energy.data_ptr(), self.grad.data_ptr(), C.byref(g)))
         return g
+
+    def close(self) -> None:
+        for g in self._graphs.values():
+            _lib.tsamd_graph_destroy(g)
+        self._graphs = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def evaluate(self, c1: float, c2: float, order: int):
         """Replay the fused evaluation with these coefficients; returns the static ``(energy, grad)`` buffers
         (``grad`` already multiplied by ``grad_scale``)."""
-        if self._last != (c1, c2):
-            k = self._ring_pos
-            self._ring_pos = (k + 1) % len(self._ring)
-            if self._ring_ev[k] is not None:
-                self._ring_ev[k].synchronize()
-            self._ring[k][0] = float(c1)
-            self._ring[k][1] = float(c2)
-            self._coef.copy_(self._ring[k], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.x.device))
-            self._ring_ev[k] = ev
-            self._last = (c1, c2)
         g = self._graphs.get(order)
         if g is None:
-            g = self._graphs[order] = self._capture(order)
-        g.replay()
+            g = self._graphs[order] = self._create(order)
+        _capi.check(_lib.tsamd_graph_launch(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device)))
         return self.energy, self.grad
 
     def step(self, it: int, c1: float | None = None, c2: float | None = None):
