@@ -267,6 +267,30 @@ int tsamd_vertex_normals(const tsamd_surface *s, const float *v_pos_dev, void *s
 int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev, const float *raw_dev,
                                   const float *grad_nrm_dev, void *workspace_dev, void *stream, float *grad_v_pos_dev);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Renderer slice (first slice): the two nvdiffrast operators the reference's renderer calls,
+ *   tsamd_rasterize            <- dr.rasterize(ctx, pos_clip, tri, resolution=[H, W], grad_db=False)[0]   renderers/mesh_rasterizer.py:103
+ *   tsamd_interpolate          <- dr.interpolate(attr, rast, tri)[0]                                     renderers/mesh_rasterizer.py:117,145,153
+ *   tsamd_interpolate_backward <- the backward of the latter w.r.t. attr and rast's (u, v)
+ * nvdiffrast is a separate library (not vendored by the reference, version unpinned): the semantics implemented are a
+ * restatement of its published algorithm, fixed in every detail by oracle/raster_oracle.py -- clip-space input, OpenGL
+ * conventions (row 0 = bottom), no culling, nearest depth, output (u, v, z/w, triangle_id + 1), 0 = background.  PARITY
+ * UNPINNED (no nvdiffrast here).  Not in this slice: antialias, the (u, v) -> position gradient of rasterize, polygon
+ * clipping (a triangle with a vertex at w <= 0 is dropped), depth peeling, `ranges`.  Stateless: the caller owns all buffers and
+ * the current HIP device is used.  pos_clip_dev: [batch, n_vertices, 4] f32; tri_dev: [n_triangles, 3] i32;
+ * rast: [batch, height, width, 4] f32; attr_dev: [attr_batch (1 or batch), n_vertices, n_channels] f32.
+ */
+int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int32_t height, int32_t width);
+int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
+                    int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *stream);
+int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
+                      const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream);
+/* grad_attr_dev ([attr_batch, n_vertices, n_channels]) is zero-filled and accumulated by the call; grad_rast_dev
+ * ([batch, height, width, 4], channels 2-3 = 0) may be NULL. */
+int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
+                               const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
+                               float *grad_attr_dev, float *grad_rast_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,222 @@
+"""float64 / integer ORACLE for the renderer slice: ``rasterize`` and ``interpolate`` --
+TEST INFRASTRUCTURE, never imported by the product path.
+
+What it restates.  The reference renders through nvdiffrast (NVlabs/nvdiffrast, NOT vendored, version unpinned:
+``import nvdiffrast.torch as dr`` at /root/reference/renderers/mesh_rasterizer.py:2) and uses exactly
+
+    rast, _ = dr.rasterize(ctx, pos_clip[B,V,4], tri[T,3], resolution=[H,W], grad_db=False)     mesh_rasterizer.py:103
+    out, _  = dr.interpolate(attr[1|B,V,C], rast, tri)                                          mesh_rasterizer.py:117,145,153
+
+The algorithm below follows nvdiffrast's PUBLISHED description (Laine et al., "Modular Primitives for High-Performance
+Differentiable Rendering", 2020, section 3.2-3.3 and the library documentation): clip-space input, OpenGL conventions
+(NDC = xyz / w, pixel (i, j) has its centre at NDC ((i + 0.5) / W * 2 - 1, (j + 0.5) / H * 2 - 1), row 0 is the BOTTOM
+row), no face culling, nearest depth wins, output ``(u, v, z/w, triangle_id + 1)`` with ``(u, v)`` the perspective-correct
+barycentrics of the triangle's first two vertices and 0 in all four channels for background, and
+``interpolate = u a0 + v a1 + (1 - u - v) a2``.
+
+PARITY UNPINNED.  nvdiffrast is not in this image and the reference holds no golden images, so nothing here is checked
+against the library itself.  Where the published description leaves a choice, this file fixes one and says so:
+
+* coverage: vertices are snapped to 1/256 pixel (round half up) and the three edge functions are evaluated EXACTLY in
+  integers at the pixel centre; a pixel on an edge belongs to the triangle whose edge is "top-left" in the y-up window
+  (after orienting the triangle counter-clockwise: dy < 0, or dy == 0 and dx < 0), so triangles sharing an edge cover
+  every pixel exactly once (nvdiffrast's CUDA rasteriser snaps to 1/16 pixel; the rule is the same kind);
+* no polygon clipping: a triangle with a vertex at w <= 0, a non-finite coordinate or a snapped coordinate beyond
+  +-2^22 sub-pixel units is dropped; fragments with z/w outside [-1, 1] are dropped per pixel;
+* depth test: z/w of the three vertices interpolated linearly in window space with the integer edge functions as weights,
+  in float64 with one fixed operation order, quantised to 32 bits; equal depth keys are resolved towards the LOWER
+  triangle index.  The GPU kernel performs the same float64 operations in the same order (IEEE basic operations are
+  correctly rounded on both sides), which is what makes the triangle ids BIT-EXACT between the two.
+* ``(u, v, z/w)`` are then recomputed from the unsnapped clip-space positions (homogeneous 2-D edge functions, as
+  nvdiffrast's fragment stage does), clamped to [0, 1] / [-1, 1]: float64 here, float32 on the GPU -- compared with a
+  tolerance.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SUBPIXEL_BITS = 8
+SUB = 1 << SUBPIXEL_BITS
+COORD_LIMIT = 1 << 22          # snapped coordinates beyond +-2^22 sub-pixel units drop the triangle
+DEPTH_SCALE = 2147483648.0     # depth key = floor((z/w + 1) * 2^31), clamped to [0, 2^32 - 1]
+NO_FRAGMENT = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def snap_vertices(pos_clip: np.ndarray, height: int, width: int):
+    """Window coordinates in 1/256 pixel (int64), NDC depth (float64) and a validity mask per vertex of one view.
+
+    Every operation is a single correctly rounded float64 operation, in this order -- the GPU kernel repeats them."""
+    p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    x, y, z, w = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    ok = np.isfinite(p).all(axis=1) & (w > 0.0)
+    ws = np.where(ok, w, 1.0)
+    xs = ((x / ws) * 0.5 + 0.5) * float(width)
+    ys = ((y / ws) * 0.5 + 0.5) * float(height)
+    X = np.floor(xs * float(SUB) + 0.5)
+    Y = np.floor(ys * float(SUB) + 0.5)
+    ok &= (np.abs(X) <= COORD_LIMIT) & (np.abs(Y) <= COORD_LIMIT)
+    X = np.where(ok, X, 0.0).astype(np.int64)
+    Y = np.where(ok, Y, 0.0).astype(np.int64)
+    zw = np.where(ok, z / ws, 0.0)
+    return X, Y, zw, ok
+
+
+def _top_left(dx: int, dy: int) -> bool:
+    return dy < 0 or (dy == 0 and dx < 0)
+
+
+def rasterize_ids(pos_clip: np.ndarray, tri: np.ndarray, height: int, width: int) -> np.ndarray:
+    """Depth keys ``(depth32 << 32) | triangle`` per pixel of ONE view, ``NO_FRAGMENT`` where nothing covers the centre."""
+    X, Y, ZW, ok = snap_vertices(pos_clip, height, width)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    key = np.full((height, width), NO_FRAGMENT, dtype=np.uint64)
+    for t in range(tri.shape[0]):
+        i0, i1, i2 = tri[t]
+        if not (ok[i0] and ok[i1] and ok[i2]):
+            continue
+        x0, y0, x1, y1, x2, y2 = int(X[i0]), int(Y[i0]), int(X[i1]), int(Y[i1]), int(X[i2]), int(Y[i2])
+        z0, z1, z2 = float(ZW[i0]), float(ZW[i1]), float(ZW[i2])
+        area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
+        if area == 0:
+            continue
+        if area < 0:                                    # orient counter-clockwise: swap vertices 1 and 2
+            x1, y1, z1, x2, y2, z2 = x2, y2, z2, x1, y1, z1
+        # pixel range whose centres can lie inside (centre of pixel i = i * 256 + 128 in sub-pixel units)
+        px0 = max(0, (min(x0, x1, x2) - SUB // 2 + SUB - 1) // SUB)
+        px1 = min(width - 1, (max(x0, x1, x2) - SUB // 2) // SUB)
+        py0 = max(0, (min(y0, y1, y2) - SUB // 2 + SUB - 1) // SUB)
+        py1 = min(height - 1, (max(y0, y1, y2) - SUB // 2) // SUB)
+        if px0 > px1 or py0 > py1:
+            continue
+        cx = (np.arange(px0, px1 + 1, dtype=np.int64) * SUB + SUB // 2)[None, :]
+        cy = (np.arange(py0, py1 + 1, dtype=np.int64) * SUB + SUB // 2)[:, None]
+        # E_k = edge function of the edge OPPOSITE vertex k (weights of vertex k), >= 0 inside
+        e0 = (x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1)
+        e1 = (x0 - x2) * (cy - y2) - (y0 - y2) * (cx - x2)
+        e2 = (x1 - x0) * (cy - y0) - (y1 - y0) * (cx - x0)
+        inside = np.ones(e0.shape, dtype=bool)
+        for e, (dx, dy) in ((e0, (x2 - x1, y2 - y1)), (e1, (x0 - x2, y0 - y2)), (e2, (x1 - x0, y1 - y0))):
+            inside &= (e > 0) | ((e == 0) & _top_left(dx, dy))
+        if not inside.any():
+            continue
+        a = (e0 + e1) + e2                                # = |2 area| at every pixel
+        zw = ((e0.astype(np.float64) * z0 + e1.astype(np.float64) * z1) + e2.astype(np.float64) * z2) / a.astype(np.float64)
+        inside &= (zw >= -1.0) & (zw <= 1.0)
+        q = np.floor((zw + 1.0) * DEPTH_SCALE)
+        q = np.clip(q, 0.0, 4294967295.0).astype(np.uint64)
+        k = (q << np.uint64(32)) | np.uint64(t)
+        sub = key[py0:py1 + 1, px0:px1 + 1]
+        np.minimum(sub, np.where(inside, k, NO_FRAGMENT), out=sub)
+    return key
+
+
+def resolve(pos_clip: np.ndarray, tri: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """``(u, v, z/w, id + 1)`` in float64 from the winning triangle of every pixel (nvdiffrast's fragment stage)."""
+    height, width = key.shape
+    p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    out = np.zeros((height, width, 4))
+    hit = key != NO_FRAGMENT
+    ids = (key & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    jj, ii = np.nonzero(hit)
+    t = ids[jj, ii]
+    fx = (ii + 0.5) / width * 2.0 - 1.0
+    fy = (jj + 0.5) / height * 2.0 - 1.0
+    v = p[tri[t]]                                          # [k, 3, 4]
+    px = v[:, :, 0] - fx[:, None] * v[:, :, 3]
+    py = v[:, :, 1] - fy[:, None] * v[:, :, 3]
+    a0 = px[:, 1] * py[:, 2] - py[:, 1] * px[:, 2]
+    a1 = px[:, 2] * py[:, 0] - py[:, 2] * px[:, 0]
+    a2 = px[:, 0] * py[:, 1] - py[:, 0] * px[:, 1]
+    s = a0 + a1 + a2
+    s = np.where(s == 0.0, 1.0, s)
+    b0, b1 = a0 / s, a1 / s
+    b2 = 1.0 - b0 - b1
+    z = b0 * v[:, 0, 2] + b1 * v[:, 1, 2] + b2 * v[:, 2, 2]
+    w = b0 * v[:, 0, 3] + b1 * v[:, 1, 3] + b2 * v[:, 2, 3]
+    out[jj, ii, 0] = np.clip(b0, 0.0, 1.0)
+    out[jj, ii, 1] = np.clip(b1, 0.0, 1.0)
+    out[jj, ii, 2] = np.clip(z / np.where(w == 0.0, 1.0, w), -1.0, 1.0)
+    out[jj, ii, 3] = t + 1.0
+    return out
+
+
+def rasterize(pos_clip: np.ndarray, tri: np.ndarray, resolution) -> np.ndarray:
+    """``dr.rasterize(ctx, pos, tri, resolution)[0]`` (mesh_rasterizer.py:103): ``[B, H, W, 4]`` float64."""
+    pos_clip = np.asarray(pos_clip, dtype=np.float32)
+    if pos_clip.ndim == 2:
+        pos_clip = pos_clip[None]
+    height, width = int(resolution[0]), int(resolution[1])
+    return np.stack([resolve(pos_clip[b], tri, rasterize_ids(pos_clip[b], tri, height, width)) for b in range(pos_clip.shape[0])])
+
+
+def interpolate(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray) -> np.ndarray:
+    """``dr.interpolate(attr, rast, tri)[0]`` (mesh_rasterizer.py:117): ``u a0 + v a1 + (1 - u - v) a2``, 0 on background."""
+    attr = np.asarray(attr, dtype=np.float64)
+    rast = np.asarray(rast, dtype=np.float64)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    B = rast.shape[0]
+    out = np.zeros(rast.shape[:3] + (attr.shape[-1],))
+    for b in range(B):
+        a = attr[b if attr.shape[0] > 1 else 0]
+        ids = rast[b, ..., 3].astype(np.int64) - 1
+        hit = ids >= 0
+        t = tri[ids[hit]]
+        u, v = rast[b, ..., 0][hit][:, None], rast[b, ..., 1][hit][:, None]
+        out[b][hit] = u * a[t[:, 0]] + v * a[t[:, 1]] + (1.0 - u - v) * a[t[:, 2]]
+    return out
+
+
+def interpolate_backward(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray, grad_out: np.ndarray):
+    """Gradients of ``interpolate`` w.r.t. ``attr`` (scatter of the barycentric weights) and w.r.t. ``rast``'s (u, v)."""
+    attr = np.asarray(attr, dtype=np.float64)
+    rast = np.asarray(rast, dtype=np.float64)
+    g = np.asarray(grad_out, dtype=np.float64)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    grad_attr = np.zeros_like(attr)
+    grad_rast = np.zeros_like(rast)
+    for b in range(rast.shape[0]):
+        ab = b if attr.shape[0] > 1 else 0
+        ids = rast[b, ..., 3].astype(np.int64) - 1
+        hit = ids >= 0
+        t = tri[ids[hit]]
+        u, v = rast[b, ..., 0][hit][:, None], rast[b, ..., 1][hit][:, None]
+        gg = g[b][hit]
+        np.add.at(grad_attr[ab], t[:, 0], u * gg)
+        np.add.at(grad_attr[ab], t[:, 1], v * gg)
+        np.add.at(grad_attr[ab], t[:, 2], (1.0 - u - v) * gg)
+        a0, a1, a2 = attr[ab][t[:, 0]], attr[ab][t[:, 1]], attr[ab][t[:, 2]]
+        du = np.sum(gg * (a0 - a2), axis=1)
+        dv = np.sum(gg * (a1 - a2), axis=1)
+        gr = grad_rast[b]
+        gr[..., 0][hit] = du
+        gr[..., 1][hit] = dv
+    return grad_attr, grad_rast
+
+
+def orbit_mvps(n_views: int, distance: float = 3.0, fov_deg: float = 40.0, near: float = 0.5, far: float = 8.0,
+               elevation_deg: float = 20.0) -> np.ndarray:
+    """``n_views`` model-view-projection matrices (float32 ``[n, 4, 4]``, OpenGL clip space) on a circle around the
+    origin -- the kind of batch /root/reference/data/*.py hands to ``MeshRasterizer.forward(mvp, ...)``."""
+    f = 1.0 / np.tan(np.radians(fov_deg) / 2.0)
+    proj = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, (far + near) / (near - far), 2 * far * near / (near - far)], [0, 0, -1, 0]])
+    out = []
+    el = np.radians(elevation_deg)
+    for k in range(n_views):
+        az = 2 * np.pi * k / n_views
+        eye = distance * np.array([np.cos(el) * np.sin(az), np.sin(el), np.cos(el) * np.cos(az)])
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(fwd, [0.0, 1.0, 0.0])
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        view = np.eye(4)
+        view[0, :3], view[1, :3], view[2, :3] = right, up, -fwd
+        view[:3, 3] = -view[:3, :3] @ eye
+        out.append(proj @ view)
+    return np.stack(out).astype(np.float32)
+
+
+def transform_pos(mvp: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """``MeshRasterizer.transform_pos`` (mesh_rasterizer.py:54-78, non-ortho branch): ``[v, 1] @ mvp^T`` per view, float32."""
+    posw = np.concatenate([np.asarray(pos, dtype=np.float32), np.ones((pos.shape[0], 1), dtype=np.float32)], axis=1)
+    return np.matmul(posw[None], np.transpose(np.asarray(mvp, dtype=np.float32), (0, 2, 1))).astype(np.float32)

@@ -1,0 +1,209 @@
+"""Renderer slice: ``tssplat_amd.dr.rasterize`` / ``interpolate`` against oracle/raster_oracle.py.
+
+CPU tests: the oracle's own invariants (watertight shared edges, orthographic interpolation reproduces the pixel grid,
+nearest depth, lower id on ties, dropped triangles) and the C ABI's argument checks.  GPU tests (``-m gpu``): triangle
+ids BIT-EXACT against the oracle, (u, v, z/w) and interpolated attributes within fp32 tolerance, interpolate backward
+against the oracle's float64 scatter.  Parity with nvdiffrast itself is UNPINNED (the library is not in this image)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import raster_oracle as R
+from tssplat_amd import _capi, scenes
+
+
+def _quad(z=0.0, w=1.0, lo=-1.0, hi=1.0):
+    pos = np.array([[lo, lo, z, 1], [hi, lo, z, 1], [hi, hi, z, 1], [lo, hi, z, 1]], dtype=np.float32)
+    pos[:, :3] *= w
+    pos[:, 3] = w
+    return pos, np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+
+
+def test_full_screen_quad_is_covered_exactly_once():
+    pos, tri = _quad()
+    for H, W in ((8, 8), (7, 13)):
+        key = R.rasterize_ids(pos, tri, H, W)
+        assert (key != R.NO_FRAGMENT).all()
+        ids = (key & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        assert set(np.unique(ids)) == {0, 1}
+        # the diagonal pixels (centre exactly on the shared edge when H == W) go to exactly one triangle: the two
+        # per-triangle rasterisations are disjoint and together cover everything
+        k0 = R.rasterize_ids(pos, tri[:1], H, W) != R.NO_FRAGMENT
+        k1 = R.rasterize_ids(pos, tri[1:], H, W) != R.NO_FRAGMENT
+        assert not (k0 & k1).any() and (k0 | k1).all()
+
+
+def test_watertight_fan_at_arbitrary_positions():
+    rng = np.random.default_rng(5)
+    H = W = 32
+    for _ in range(20):
+        # a fan of triangles around an interior point: shared edges at random orientations, pixel centres on edges included
+        c = rng.uniform(-0.3, 0.3, 2)
+        ring = [c + rng.uniform(0.4, 0.7) * np.array([np.cos(a), np.sin(a)])
+                for a in 2 * np.pi * np.arange(7) / 7 + rng.uniform(-0.3, 0.3, 7)]          # (every wedge well under 180 degrees)
+        pts = np.array([c] + ring)
+        pts = np.round(pts * 16) / 16                              # many coordinates land exactly on pixel centres / edges
+        pos = np.concatenate([pts, np.zeros((8, 1)), np.ones((8, 1))], axis=1).astype(np.float32)
+        tri = np.array([[0, 1 + k, 1 + (k + 1) % 7] for k in range(7)], dtype=np.int32)
+        cover = sum((R.rasterize_ids(pos, tri[k:k + 1], H, W) != R.NO_FRAGMENT).astype(int) for k in range(7))
+        assert cover.max() <= 1                                    # never twice
+        union = R.rasterize_ids(pos, tri, H, W) != R.NO_FRAGMENT
+        assert np.array_equal(union, cover == 1)
+
+
+def test_orthographic_interpolation_reproduces_pixel_centres_and_depth_order():
+    H, W = 16, 24
+    pos, tri = _quad(z=0.25)
+    rast = R.rasterize(pos, tri, (H, W))
+    attr = pos[None, :, :2].astype(np.float64)
+    out = R.interpolate(attr, rast, tri)
+    fx = (np.arange(W) + 0.5) / W * 2 - 1
+    fy = (np.arange(H) + 0.5) / H * 2 - 1
+    assert np.allclose(out[0, ..., 0], fx[None, :], atol=1e-12) and np.allclose(out[0, ..., 1], fy[:, None], atol=1e-12)
+    assert np.allclose(rast[0, ..., 2], 0.25)
+    # a nearer, smaller quad in front wins where it covers; an identical copy at the SAME depth loses to the lower id
+    pos2, tri2 = _quad(z=-0.5, lo=-0.5, hi=0.5)
+    both_pos = np.concatenate([pos, pos2, pos])
+    both_tri = np.concatenate([tri, tri2 + 4, tri + 8])
+    r2 = R.rasterize(both_pos, both_tri, (H, W))
+    ids = r2[0, ..., 3].astype(int) - 1
+    inner = (np.abs(fx)[None, :] < 0.5) & (np.abs(fy)[:, None] < 0.5)
+    assert np.isin(ids[inner], [2, 3]).all() and np.isin(ids[~inner], [0, 1]).all()
+    assert np.allclose(r2[0, ..., 2][inner], -0.5)
+
+
+def test_dropped_triangles_and_background():
+    H = W = 8
+    pos, tri = _quad()
+    behind = pos.copy()
+    behind[0, 3] = -1.0                                             # a vertex behind the eye: no clipping in this slice, dropped
+    assert (R.rasterize(behind, tri[:1], (H, W)) == 0).all()
+    far = pos.copy()
+    far[:, 2] = 2.0                                                 # z/w = 2: beyond the far plane, every fragment dropped
+    assert (R.rasterize(far, tri, (H, W)) == 0).all()
+    nan = pos.copy()
+    nan[1, 0] = np.nan
+    assert (R.rasterize(nan, tri[:1], (H, W)) == 0).all()
+    degenerate = np.array([[0, 1, 1]], dtype=np.int32)
+    assert (R.rasterize(pos, degenerate, (H, W)) == 0).all()
+
+
+def test_interpolate_backward_is_the_adjoint():
+    rng = np.random.default_rng(2)
+    pos, tri = _quad(w=2.0)
+    rast = R.rasterize(pos, tri, (6, 6))
+    attr = rng.standard_normal((1, 4, 3))
+    g = rng.standard_normal((1, 6, 6, 3))
+    ga, gr = R.interpolate_backward(attr, rast, tri, g)
+    d = rng.standard_normal(attr.shape)
+    lhs = np.sum(R.interpolate(attr + 1e-6 * d, rast, tri) * g) - np.sum(R.interpolate(attr - 1e-6 * d, rast, tri) * g)
+    assert abs(lhs / 2e-6 - np.sum(ga * d)) <= 1e-6 * abs(np.sum(ga * d)) + 1e-9
+    r2 = rast.copy()
+    r2[..., 0] += 1e-6
+    du = (np.sum(R.interpolate(attr, r2, tri) * g) - np.sum(R.interpolate(attr, rast, tri) * g)) / 1e-6
+    assert abs(du - gr[..., 0].sum()) <= 1e-5 * abs(du) + 1e-8
+
+
+def test_c_abi_rejects_bad_arguments():
+    lib = _capi.load()
+    assert lib.tsamd_rasterize_workspace_bytes(8, 512, 512) == 8 * 512 * 512 * 8
+    assert lib.tsamd_rasterize_workspace_bytes(-1, 4, 4) == -1
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None) == 1          # null workspace / output
+    assert b"null" in lib.tsamd_last_error()
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 20000, 4, None, None, None) == 1
+    assert lib.tsamd_interpolate(None, 2, 3, 3, None, None, 4, 4, 4, None, None) == 1     # attr_batch neither 1 nor batch
+    assert lib.tsamd_interpolate_backward(None, 1, 3, 0, None, None, 1, 4, 4, None, None, None, None) == 1
+    # empty images are fine without any pointer
+    assert lib.tsamd_rasterize(None, 0, 0, None, 0, 0, 0, None, None, None) == 0
+
+
+# ------------------------------------------------------------------ GPU parity ------------------------------------------------------------------
+
+def _surface_scene(kind, spheres, n_views, seed=0):
+    """Boundary triangles of a tet-sphere scene (what get_surface_vf hands the reference's renderer) + orbit cameras."""
+    from tssplat_amd import geometry
+    sc = scenes.make_scene(kind, spheres, seed=seed)
+    vid, faces = geometry.get_surface_vf(sc.tets)
+    v = scenes.deform(sc, 0.05, seed=seed + 1)[np.asarray(vid)]
+    mvp = R.orbit_mvps(n_views)
+    return R.transform_pos(mvp, v), np.asarray(faces, dtype=np.int32), v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,spheres,views,res", [("kuhn4", 3, 2, (48, 64)), ("kuhn8", 6, 3, (128, 128)), ("kuhn19", 2, 1, (256, 256))])
+def test_rasterize_ids_bit_exact_and_barycentrics(kind, spheres, views, res):
+    import torch
+    import tssplat_amd.dr as dr
+    pos_clip, tri, _ = _surface_scene(kind, spheres, views)
+    ref = R.rasterize(pos_clip, tri, res)
+    ctx = dr.RasterizeCudaContext()
+    rast, db = dr.rasterize(ctx, torch.from_numpy(pos_clip).cuda(), torch.from_numpy(tri).cuda(), resolution=list(res), grad_db=False)
+    assert rast.shape == (views, res[0], res[1], 4) and db.shape[-1] == 0
+    got = rast.cpu().numpy().astype(np.float64)
+    assert (ref[..., 3] > 0).mean() > 0.02                                       # the scene is in view
+    assert np.array_equal(got[..., 3], ref[..., 3]), "triangle ids must be bit-exact"
+    hit = ref[..., 3] > 0
+    assert np.abs(got[..., :2][hit] - ref[..., :2][hit]).max() <= 2e-4           # fp32 barycentrics of tiny triangles
+    assert np.abs(got[..., 2][hit] - ref[..., 2][hit]).max() <= 2e-6
+    assert (got[~hit] == 0).all()
+    # a second call through the same context (workspace reuse) is identical
+    rast2, _ = dr.rasterize(ctx, torch.from_numpy(pos_clip).cuda(), torch.from_numpy(tri).cuda(), resolution=list(res), grad_db=False)
+    assert torch.equal(rast, rast2)
+
+
+@pytest.mark.gpu
+def test_rasterize_edge_cases_on_gpu():
+    import torch
+    import tssplat_amd.dr as dr
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(3)
+    # shared edges through pixel centres, equal-depth duplicates, a vertex behind the eye, NaN, a degenerate and an off-screen triangle
+    pts = np.round(rng.uniform(-1.2, 1.2, (40, 2)) * 8) / 8
+    w = rng.uniform(0.5, 3.0, 40).astype(np.float32)
+    pos = np.concatenate([pts * w[:, None], (rng.uniform(-0.9, 0.9, 40) * w)[:, None], w[:, None]], axis=1).astype(np.float32)
+    pos[5, 3] = -0.5
+    pos[9, 1] = np.nan
+    tri = rng.integers(0, 40, (120, 3)).astype(np.int32)
+    tri = np.concatenate([tri, tri[:10], [[1, 1, 2]]]).astype(np.int32)          # duplicates (ties -> lower id) and a degenerate one
+    pos = np.stack([pos, pos[::-1].copy()])
+    for res in ((16, 16), (33, 20)):
+        ref = R.rasterize(pos, tri, res)
+        rast, _ = dr.rasterize(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), resolution=list(res), grad_db=False)
+        got = rast.cpu().numpy().astype(np.float64)
+        assert np.array_equal(got[..., 3], ref[..., 3])
+        hit = ref[..., 3] > 0
+        assert hit.any() and np.abs(got[..., :3][hit] - ref[..., :3][hit]).max() <= 5e-4
+    with pytest.raises(NotImplementedError):
+        dr.rasterize(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), resolution=[8, 8])        # grad_db defaults to True
+    with pytest.raises(NotImplementedError):
+        dr.antialias(None, None, None, None)
+    with pytest.raises(RuntimeError):
+        dr.rasterize(ctx, torch.from_numpy(pos), torch.from_numpy(tri), resolution=[8, 8], grad_db=False)       # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("attr_batch_is_one", [True, False])
+def test_interpolate_forward_backward(attr_batch_is_one):
+    import torch
+    import tssplat_amd.dr as dr
+    views, res = 3, (96, 96)
+    pos_clip, tri, v = _surface_scene("kuhn8", 5, views)
+    ctx = dr.RasterizeCudaContext()
+    tri_d = torch.from_numpy(tri).cuda()
+    rast, _ = dr.rasterize(ctx, torch.from_numpy(pos_clip).cuda(), tri_d, resolution=list(res), grad_db=False)
+    rng = np.random.default_rng(1)
+    attr_np = (v[None] if attr_batch_is_one else np.stack([v * (1 + 0.1 * k) for k in range(views)])).astype(np.float32)
+    attr = torch.from_numpy(attr_np).cuda().requires_grad_(True)
+    rast_in = rast.clone().requires_grad_(True)
+    out, da = dr.interpolate(attr, rast_in, tri_d)
+    assert out.shape == (views, res[0], res[1], 3) and da.shape[-1] == 0
+    rast_np = rast.cpu().numpy()
+    ref = R.interpolate(attr_np, rast_np, tri)
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).cuda())
+    ga, gr = R.interpolate_backward(attr_np, rast_np, tri, g)
+    assert np.abs(attr.grad.cpu().numpy() - ga).max() <= 2e-5 * np.abs(ga).max()            # fp32 atomics, arbitrary order
+    assert np.abs(rast_in.grad.cpu().numpy() - gr).max() <= 2e-5 * max(np.abs(gr).max(), 1e-30)
+    assert (rast_in.grad[..., 2:] == 0).all()

@@ -97,6 +97,14 @@ SIGNATURES = {
                                         C.c_float, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
     "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    # renderer slice
+    "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "tsamd_rasterize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "tsamd_interpolate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p]),
+    "tsamd_interpolate_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                             C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     # surface glue
     "tsamd_extract_surface": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
                                       C.POINTER(C.c_int64)]),

@@ -1,0 +1,74 @@
+// C ABI of the renderer slice (include/tssplat_amd.h, "renderer" section): stateless entry points, the caller owns
+// every buffer (positions, triangles, the depth-key workspace, outputs) and names the device by making it current.
+#include <string>
+
+#include "capi_common.h"
+#include "raster.h"
+
+using tsamd::capi_fail;
+
+namespace {
+
+int check_image(int64_t batch, int32_t height, int32_t width)
+{
+    if (batch < 0 || height < 0 || width < 0 || height > 16384 || width > 16384)
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch / height / width out of range (0 .. 16384 pixels per side)");
+    return TSAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int32_t height, int32_t width)
+{
+    if (batch < 0 || height < 0 || width < 0) return -1;
+    return batch * int64_t(height) * int64_t(width) * 8;
+}
+
+int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles, int32_t height,
+                    int32_t width, void *workspace_dev, float *rast_out_dev, void *stream)
+{
+    int rc = check_image(batch, height, width);
+    if (rc) return rc;
+    if (n_vertices < 0 || n_triangles < 0 || n_triangles >= (int64_t(1) << 32) - 1)
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or more than 2^32 - 2 triangles (the id shares a 64-bit key with the depth)");
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (pixels > 0 && (!workspace_dev || !rast_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "workspace_dev / rast_out_dev is null");
+    if (batch * n_triangles > 0 && (!pos_clip_dev || !tri_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev is null");
+    TSAMD_HIP(tsamd::launch_rasterize(pos_clip_dev, batch, n_vertices, tri_dev, n_triangles, height, width, workspace_dev, rast_out_dev,
+                                      static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
+                      const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream)
+{
+    int rc = check_image(batch, height, width);
+    if (rc) return rc;
+    if (n_vertices < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1");
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (pixels > 0 && (!attr_dev || !rast_dev || !tri_dev || !out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
+    TSAMD_HIP(tsamd::launch_interpolate(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, batch, height, width, out_dev,
+                                        static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
+                               const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
+                               float *grad_attr_dev, float *grad_rast_dev, void *stream)
+{
+    int rc = check_image(batch, height, width);
+    if (rc) return rc;
+    if (n_vertices < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1");
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (attr_batch * n_vertices > 0 && !grad_attr_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_attr_dev is null");
+    if (pixels > 0 && (!attr_dev || !rast_dev || !tri_dev || !grad_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
+    TSAMD_HIP(tsamd::launch_interpolate_backward(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, batch, height, width,
+                                                 grad_out_dev, grad_attr_dev, grad_rast_dev, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,240 @@
+// gfx950 kernels of the renderer slice: rasterize + interpolate, the two nvdiffrast operators
+// /root/reference/renderers/mesh_rasterizer.py:103,117,145,153 calls.  First slice: forward rasterisation (triangle
+// id, perspective-correct barycentrics, z/w), interpolate forward and backward.  No antialias, no rasterize backward.
+//
+// The specification these kernels implement is oracle/raster_oracle.py (a restatement of nvdiffrast's published
+// algorithm with every open choice fixed there); coverage and the depth test repeat its float64 / integer operations
+// one by one, which is what makes the triangle ids bit-exact against it.
+//
+//   rasterize_bin_kernel   one lane per (view, triangle): snap, set up the three integer edge functions, walk the
+//                          pixel centres of the bounding box, 64-bit atomicMin of (depth32 << 32 | triangle) per pixel
+//   rasterize_resolve_kernel  one lane per pixel: winning triangle -> (u, v, z/w, id + 1)
+//   interpolate_kernel / interpolate_backward_kernel  one lane per pixel
+//
+// Bound: HBM / L2 atomics (12 B of indices + 3 x 16 B of clip-space vertices per triangle and view, 8 B of key and 16 B of
+// output per pixel); no MFMA anywhere.
+#include <hip/hip_runtime.h>
+
+#include "raster.h"
+
+namespace tsamd {
+namespace {
+
+constexpr int kSubBits = 8;
+constexpr long long kSub = 1ll << kSubBits;
+constexpr long long kCoordLimit = 1ll << 22;
+constexpr unsigned long long kNoFragment = 0xFFFFFFFFFFFFFFFFull;
+
+struct Snapped {
+    long long x, y;
+    double zw;
+    bool ok;
+};
+
+// oracle/raster_oracle.py::snap_vertices, operation by operation (explicitly rounded double intrinsics: no contraction)
+__device__ __forceinline__ Snapped snap(const float4 p, double width, double height)
+{
+    Snapped s;
+    const double x = double(p.x), y = double(p.y), z = double(p.z), w = double(p.w);
+    s.ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w) && p.w > 0.f;
+    const double ws = s.ok ? w : 1.0;
+    const double xs = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(x, ws), 0.5), 0.5), width);
+    const double ys = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(y, ws), 0.5), 0.5), height);
+    const double X = floor(__dadd_rn(__dmul_rn(xs, double(kSub)), 0.5));
+    const double Y = floor(__dadd_rn(__dmul_rn(ys, double(kSub)), 0.5));
+    s.ok = s.ok && fabs(X) <= double(kCoordLimit) && fabs(Y) <= double(kCoordLimit);
+    s.x = s.ok ? (long long)X : 0;
+    s.y = s.ok ? (long long)Y : 0;
+    s.zw = s.ok ? __ddiv_rn(z, ws) : 0.0;
+    return s;
+}
+
+__device__ __forceinline__ bool top_left(long long dx, long long dy) { return dy < 0 || (dy == 0 && dx < 0); }
+
+__global__ __launch_bounds__(256) void rasterize_bin_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
+                                                            int64_t batch, int height, int width, unsigned long long *keys)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= batch * n_tri) return;
+    const int64_t b = gid / n_tri, t = gid - b * n_tri;
+    const int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) return;
+    const float4 *pv = pos + b * n_vertices;
+    const Snapped s0 = snap(pv[i0], double(width), double(height));
+    Snapped s1 = snap(pv[i1], double(width), double(height)), s2 = snap(pv[i2], double(width), double(height));
+    if (!(s0.ok && s1.ok && s2.ok)) return;
+    const long long area = (s1.x - s0.x) * (s2.y - s0.y) - (s1.y - s0.y) * (s2.x - s0.x);
+    if (area == 0) return;
+    if (area < 0) {   // orient counter-clockwise
+        const Snapped tmp = s1;
+        s1 = s2;
+        s2 = tmp;
+    }
+    const long long minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
+    const long long miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
+    // pixel i has its centre at i * 256 + 128; >> is an arithmetic shift (floor) on negative values
+    const long long px0 = max(0ll, (minx - kSub / 2 + kSub - 1) >> kSubBits), px1 = min((long long)width - 1, (maxx - kSub / 2) >> kSubBits);
+    const long long py0 = max(0ll, (miny - kSub / 2 + kSub - 1) >> kSubBits), py1 = min((long long)height - 1, (maxy - kSub / 2) >> kSubBits);
+    if (px0 > px1 || py0 > py1) return;
+    // E_k = edge function of the edge opposite vertex k, >= 0 inside; d/dx = -(dy) * 256 per pixel, d/dy = dx * 256
+    const long long dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
+    const bool tl0 = top_left(dx0, dy0), tl1 = top_left(dx1, dy1), tl2 = top_left(dx2, dy2);
+    const long long cx0 = px0 * kSub + kSub / 2, cy0 = py0 * kSub + kSub / 2;
+    long long r0 = dx0 * (cy0 - s1.y) - dy0 * (cx0 - s1.x);
+    long long r1 = dx1 * (cy0 - s2.y) - dy1 * (cx0 - s2.x);
+    long long r2 = dx2 * (cy0 - s0.y) - dy2 * (cx0 - s0.x);
+    unsigned long long *kb = keys + size_t(b) * size_t(height) * size_t(width);
+    for (long long py = py0; py <= py1; ++py) {
+        long long e0 = r0, e1 = r1, e2 = r2;
+        for (long long px = px0; px <= px1; ++px) {
+            const bool in = (e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2));
+            if (in) {
+                const double a = double((e0 + e1) + e2);
+                const double num = __dadd_rn(__dadd_rn(__dmul_rn(double(e0), s0.zw), __dmul_rn(double(e1), s1.zw)), __dmul_rn(double(e2), s2.zw));
+                const double zw = __ddiv_rn(num, a);
+                if (zw >= -1.0 && zw <= 1.0) {
+                    double q = floor(__dmul_rn(__dadd_rn(zw, 1.0), 2147483648.0));
+                    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
+                    const unsigned long long key = ((unsigned long long)q << 32) | (unsigned long long)t;
+                    atomicMin(kb + size_t(py) * size_t(width) + size_t(px), key);
+                }
+            }
+            e0 -= dy0 * kSub;
+            e1 -= dy1 * kSub;
+            e2 -= dy2 * kSub;
+        }
+        r0 += dx0 * kSub;
+        r1 += dx1 * kSub;
+        r2 += dx2 * kSub;
+    }
+}
+
+// nvdiffrast's fragment stage: barycentrics from the UNSNAPPED clip-space positions (homogeneous 2-D edge functions),
+// perspective-correct by construction; oracle/raster_oracle.py::resolve in float32.
+__global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t batch,
+                                                                int height, int width, const unsigned long long *keys, float4 *rast)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t hw = int64_t(height) * width;
+    if (gid >= batch * hw) return;
+    const unsigned long long key = keys[gid];
+    if (key == kNoFragment) {
+        rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int64_t b = gid / hw, pix = gid - b * hw;
+    const int py = int(pix / width), px = int(pix - int64_t(py) * width);
+    const int64_t t = int64_t(key & 0xFFFFFFFFull);
+    const float4 *pv = pos + b * n_vertices;
+    const float4 v0 = pv[tri[3 * t]], v1 = pv[tri[3 * t + 1]], v2 = pv[tri[3 * t + 2]];
+    const float fx = (float(px) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py) + 0.5f) / float(height) * 2.f - 1.f;
+    const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
+    const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
+    const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    float s = a0 + a1 + a2;
+    s = s == 0.f ? 1.f : s;
+    const float b0 = a0 / s, b1 = a1 / s, b2 = 1.f - b0 - b1;
+    const float z = b0 * v0.z + b1 * v1.z + b2 * v2.z;
+    float w = b0 * v0.w + b1 * v1.w + b2 * v2.w;
+    w = w == 0.f ? 1.f : w;
+    rast[gid] = make_float4(fminf(fmaxf(b0, 0.f), 1.f), fminf(fmaxf(b1, 0.f), 1.f), fminf(fmaxf(z / w, -1.f), 1.f), float(t + 1));
+}
+
+__global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
+                                                          const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw, float *out)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= batch * hw) return;
+    const float4 r = rast[gid];
+    float *o = out + gid * channels;
+    const int64_t t = int64_t(r.w) - 1;
+    if (t < 0) {
+        for (int c = 0; c < channels; ++c) o[c] = 0.f;
+        return;
+    }
+    const int64_t b = gid / hw;
+    const float *a = attr + (attr_batch > 1 ? b : 0) * n_vertices * channels;
+    const float *a0 = a + int64_t(tri[3 * t]) * channels, *a1 = a + int64_t(tri[3 * t + 1]) * channels, *a2 = a + int64_t(tri[3 * t + 2]) * channels;
+    const float u = r.x, v = r.y, w = 1.f - r.x - r.y;
+    for (int c = 0; c < channels; ++c) o[c] = u * a0[c] + v * a1[c] + w * a2[c];
+}
+
+// d out / d attr: scatter of the three barycentric weights (fp32 global atomics: the order of the additions, and so the
+// last bits of the result, vary from run to run -- like nvdiffrast's own backward); d out / d (u, v) per pixel.
+__global__ __launch_bounds__(256) void interpolate_backward_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
+                                                                   const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw,
+                                                                   const float *grad_out, float *grad_attr, float4 *grad_rast)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= batch * hw) return;
+    const float4 r = rast[gid];
+    const int64_t t = int64_t(r.w) - 1;
+    if (t < 0) {
+        if (grad_rast) grad_rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int64_t b = gid / hw;
+    const int64_t base = (attr_batch > 1 ? b : 0) * n_vertices * channels;
+    const int64_t o0 = base + int64_t(tri[3 * t]) * channels, o1 = base + int64_t(tri[3 * t + 1]) * channels, o2 = base + int64_t(tri[3 * t + 2]) * channels;
+    const float u = r.x, v = r.y, w = 1.f - r.x - r.y;
+    const float *g = grad_out + gid * channels;
+    float du = 0.f, dv = 0.f;
+    for (int c = 0; c < channels; ++c) {
+        const float gc = g[c];
+        atomicAdd(grad_attr + o0 + c, u * gc);
+        atomicAdd(grad_attr + o1 + c, v * gc);
+        atomicAdd(grad_attr + o2 + c, w * gc);
+        const float a2 = attr[o2 + c];
+        du += gc * (attr[o0 + c] - a2);
+        dv += gc * (attr[o1 + c] - a2);
+    }
+    if (grad_rast) grad_rast[gid] = make_float4(du, dv, 0.f, 0.f);
+}
+
+unsigned blocks_for(int64_t n) { return unsigned((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vertices, const int32_t *tri, int64_t n_tri, int height, int width,
+                            void *workspace, float *rast, hipStream_t stream)
+{
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (pixels <= 0) return hipSuccess;
+    unsigned long long *keys = static_cast<unsigned long long *>(workspace);
+    hipError_t e = hipMemsetAsync(keys, 0xFF, size_t(pixels) * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (batch * n_tri > 0) {
+        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(blocks_for(batch * n_tri)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
+                           n_vertices, n_tri, batch, height, width, keys);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
+                       n_vertices, batch, height, width, keys, reinterpret_cast<float4 *>(rast));
+    return hipGetLastError();
+}
+
+hipError_t launch_interpolate(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
+                              int64_t batch, int height, int width, float *out, hipStream_t stream)
+{
+    const int64_t hw = int64_t(height) * width;
+    if (batch * hw <= 0) return hipSuccess;
+    hipLaunchKernelGGL(interpolate_kernel, dim3(blocks_for(batch * hw)), dim3(256), 0, stream, attr, attr_batch, n_vertices, channels,
+                       reinterpret_cast<const float4 *>(rast), tri, batch, hw, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_interpolate_backward(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
+                                       int64_t batch, int height, int width, const float *grad_out, float *grad_attr, float *grad_rast,
+                                       hipStream_t stream)
+{
+    const int64_t hw = int64_t(height) * width;
+    hipError_t e = hipMemsetAsync(grad_attr, 0, size_t(attr_batch) * size_t(n_vertices) * size_t(channels) * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    if (batch * hw <= 0) return hipSuccess;
+    hipLaunchKernelGGL(interpolate_backward_kernel, dim3(blocks_for(batch * hw)), dim3(256), 0, stream, attr, attr_batch, n_vertices, channels,
+                       reinterpret_cast<const float4 *>(rast), tri, batch, hw, grad_out, grad_attr, reinterpret_cast<float4 *>(grad_rast));
+    return hipGetLastError();
+}
+
+}  // namespace tsamd
