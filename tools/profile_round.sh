@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r02'
 # Raw output lands in gpurun_out/<round>p/; tools/summarize_prof.py condenses it into profiles/.
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${ROUND}p
 mkdir -p $OUT
@@ -27,6 +27,13 @@ for cfg in "kuhn19 256" "kuhn8 256" "kuhn8 64"; do set -- $cfg
   python bench.py --scene $1 --spheres $2 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_$1x$2.json 2> $OUT/bench_$1x$2.log
 done
 python bench.py --gpus 2 --dist-backend gloo --all-ranks-on-device0 --steps 20 --warmup 5 > $OUT/bench_2rank_dev0.json 2> $OUT/bench_2rank_dev0.log
+# renderer slice: kernel stats of the raster bench
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_raster -- python $R/tools/bench_raster.py --reps 5 > $OUT/stats_raster.log 2>&1)
+python tools/bench_raster.py > $OUT/bench_raster.json 2> $OUT/bench_raster.log
+# per-phase shader-clock stamps and stage ablations of the tile kernel (ablation build), two and one workgroups per CU
+python tools/ablate.py --spheres 512 --reps 10 > $OUT/ablate_512.log 2>&1
+python tools/ablate.py --spheres 512 --reps 5 --masks 0 --lds-request 100000 > $OUT/ablate_512_1wg.log 2>&1
+python tools/scaling_model.py $ROUND --out $OUT/scaling_model.json > $OUT/scaling_model.log 2>&1
 # drop the bulky per-dispatch traces, keep stats + counters
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 ls $OUT | head -50

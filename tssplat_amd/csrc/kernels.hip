@@ -611,13 +611,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     for (int c = 0; c < 9; ++c) P[c] *= q_scale;
                 }
                 if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    {   // rare path: fetch the vertex offsets again instead of pinning them (the address is rebuilt from an
-                        // opaque copy of the lane id, or it would be kept in two VGPRs from the stream phase on)
-                        int lt2 = lt;
-                        asm volatile("" : "+v"(lt2));
-                        q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
-                        q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt2);
-                    }
+                    // (the vertex offsets stay in registers from the stream phase on.  Round 2 re-fetched them here from HBM / L2
+                    // "on the rare path" to save four VGPRs -- but the path is rare per TET, not per WAVE: with 1.5 % of the
+                    // headline scene's tets inverted, 63 % of all wave-slots take it, and each paid a global-memory round trip
+                    // in the middle of pass 3.  Keeping them costs one VGPR (78) and no scratch: tile kernel 0.4633 -> 0.4324 ms
+                    // at sigma = 0.02, 0.4793 -> 0.4330 ms at sigma = 0.3; profiles/r03_experiments.md.)
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
                     slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
