@@ -615,7 +615,15 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     // "on the rare path" to save four VGPRs -- but the path is rare per TET, not per WAVE: with 1.5 % of the
                     // headline scene's tets inverted, 63 % of all wave-slots take it, and each paid a global-memory round trip
                     // in the middle of pass 3.  Keeping them costs one VGPR (78) and no scratch: tile kernel 0.4633 -> 0.4324 ms
-                    // at sigma = 0.02, 0.4793 -> 0.4330 ms at sigma = 0.3; profiles/r03_experiments.md.)
+                    // at sigma = 0.02, 0.4793 -> 0.4330 ms at sigma = 0.3; profiles/r03_experiments.md.  The explicit-operator
+                    // build has no register left for them -- it would spill two -- and still re-fetches.)
+                    if (WEIGHTED) {   // (the address is rebuilt from an opaque copy of the lane id, or it would be kept in two VGPRs
+                                      // from the stream phase on)
+                        int lt2 = lt;
+                        asm volatile("" : "+v"(lt2));
+                        q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
+                        q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt2);
+                    }
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
                     slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
