@@ -214,6 +214,7 @@ tsamd::EvalArgs eval_args(tsamd_handle *h, const float *x, const float *grad_out
     a.n_finish = int64_t(h->plan.fin_vid.size());
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
+    a.vert_stride = h->plan.vert_stride;
     a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
     a.rebuild = h->plan.n_planes == tsamd::kPlanesRebuild;
     a.dbg = h->dbg;

@@ -17,6 +17,7 @@ struct EvalArgs {
     const int32_t *fin_vid, *fin_off, *fin_idx;
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
+    int32_t vert_stride = 0;      // gvid entries per tile (Plan::vert_stride)
     bool rebuild = false;         // the plan keeps rest positions instead of the Dm^-1 planes (kPlanesRebuild)
     bool weighted = false;        // the plan carries an explicit element operator (22 planes per slot)
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production

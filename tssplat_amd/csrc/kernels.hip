@@ -274,6 +274,7 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
+    int vert_stride;   // gvid entries per tile: tile t's vertex ids start at t * vert_stride (= its descriptor's vert_off)
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
     long long *clk;  // ablation builds: 16 shader-clock stamps per wave (up to 16 waves) per tile
 };
@@ -309,7 +310,7 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
 // prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
 // within noise: DESIGN.md section 4.)
 template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD>
-__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP)
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP, int32_t gv0)
 {
     constexpr int SPT = kSlotsPerLane;
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
@@ -318,13 +319,14 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     typedef uint32_t VU __attribute__((ext_vector_type(SPT)));
     typedef float VF __attribute__((ext_vector_type(SPT)));
     static_assert(!(REBUILD && WEIGHTED), "rebuild_dminv is built for the built-in operator");
-    // 2 slots per lane: a slot's own F stays in registers from pass 1 to pass 2 instead of being read back from LDS
-    // (-8 LDS cycles per 64 slots, tile kernel -0.9 %).  Keeping the own H for pass 3 as well was measured: both slots
-    // spill 3 dwords, one slot alone gains 0.5 % and nothing on top of the F variant (profiles/r02_experiments.md).
+    // A slot's own F stays in registers from pass 1 to pass 2, and its own H from pass 2 to pass 3, instead of being read
+    // back from LDS (F: -8 LDS cycles per 64 slots, tile kernel -0.9 %, round 2; H: spilled in round 2, fits since the
+    // pruned build -- 78 VGPRs, no scratch -- tile kernel 0.4325 -> 0.4310 ms).  The explicit-operator build reads both back
+    // (its weights take the registers).
 #ifdef TSAMD_KEEP_OWN
     constexpr int kKeepF = TSAMD_KEEP_OWN & 1 ? SPT : 0, kKeepH = TSAMD_KEEP_OWN & 2 ? SPT : (TSAMD_KEEP_OWN & 4 ? 1 : 0);
 #else
-    constexpr int kKeepF = SPT, kKeepH = 0;
+    constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;
 #endif
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -352,7 +354,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // The position gather is a chain of two dependent loads (vertex id, then x).  vmcnt retires in order, so the
     // id load goes out FIRST: the wait for it then does not include the 13 plane loads, and the x loads travel
     // together with the planes instead of behind them.
-    int32_t gv0 = g_gvid[td.vert_off + (tid < td.n_verts ? tid : 0)];
+#ifdef TSAMD_LATE_GVID   // round-2 form: address from the descriptor (one more dependent memory latency at the head of a tile)
+    gv0 = g_gvid[td.vert_off + (tid < td.n_verts ? tid : 0)];
+#endif
+    // (otherwise the id was requested by the kernel's first instructions, ahead of the descriptor fetch -- see there)
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     VF dm[9];
@@ -761,8 +766,14 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     // which configure_kernels() verifies on the host.  A run-time check here costs more than it looks: a trap in the
     // prologue turns the descriptor loads into vector loads and their 12 dwords, and every address derived from them,
     // into VGPRs -- measured +26 VGPRs.)
+    // The position gather is the longest dependent chain at the head of a tile: vertex id -> position -> LDS.  The id's
+    // address needs only the tile number and a kernel argument (vertex ids sit at tile * vert_stride, plan.cpp), so it is
+    // requested HERE, before the tile descriptor is even asked for: the chain is two memory latencies instead of three.
+    // Entries beyond n_verts name vertex 0 and are never used.
+    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];
+    __builtin_amdgcn_sched_barrier(0);
     const TileDesc td0 = a.tiles[tile];
-    tile_body<WITH_GRAD, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3);
+    tile_body<WITH_GRAD, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3, gv0);
 }
 
 struct FinishArgs {
@@ -1108,6 +1119,7 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
         k.order = e.order;
         k.n_tiles = int(e.n_tiles);
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
+        k.vert_stride = e.vert_stride;
         k.dbg = e.dbg;
         k.clk = e.clk;
         if (e.block_threads > kTileThreads) return hipErrorInvalidConfiguration;

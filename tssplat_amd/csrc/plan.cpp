@@ -679,6 +679,12 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     P.slot_base.resize(size_t(T) + 1);
     int64_t blob_bytes = 0, vert_off = 0, stage_off = 0, slot_off = 0;
     int32_t max_quads = 1;
+    // Every tile's vertex ids sit at tile * vert_stride: the kernel can issue the id load of the position gather -- the
+    // head of its longest dependent chain (ids -> positions -> LDS) -- from the workgroup index alone, in parallel with
+    // the tile descriptor's fetch instead of behind it (unused entries name vertex 0).
+    int64_t vert_stride = 64;
+    for (int64_t t = 0; t < T; ++t) vert_stride = std::max<int64_t>(vert_stride, (int64_t(tile_verts[size_t(t)].size()) + 63) & ~int64_t(63));
+    P.vert_stride = int32_t(vert_stride);
     for (int64_t t = 0; t < T; ++t) {
         TileDesc &d = P.tiles[size_t(t)];
         std::memset(&d, 0, sizeof(d));
@@ -701,7 +707,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         blob_bytes += ((rebuild ? tile_rest_offset(n_planes, d.s_pad, d.n_inc4, d.n_verts) + 16 * int64_t(d.n_verts)
                                 : int64_t(n_planes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1)) + 127) &
                       ~int64_t(127);
-        vert_off += d.n_verts;
+        vert_off += vert_stride;
+        P.total_tile_verts += d.n_verts;
         stage_off += d.n_verts - d.n_excl;
         P.slot_base[size_t(t)] = slot_off;
         slot_off += d.s_pad;
@@ -716,7 +723,6 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     }
     P.slot_base[size_t(T)] = slot_off;
-    P.total_tile_verts = vert_off;
     P.n_stage = stage_off;
     P.block_threads = std::min(max_threads, ((max_quads + 63) / 64) * 64);
     P.blob.resize(size_t(blob_bytes / 4));   // (uninitialised: every tile zero-fills its own range in pass B)
@@ -740,6 +746,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 S.vert_local[tv[size_t(i)]] = i;
                 P.gvid[size_t(d.vert_off) + size_t(i)] = tv[size_t(i)];
             }
+            std::fill_n(P.gvid.data() + d.vert_off + d.n_verts, size_t(P.vert_stride - d.n_verts), int32_t(0));   // unused entries: vertex 0
             const int32_t nq = d.s_pad / spt;
             // shuffle: item L -> item (L * stride) mod n_slots with an odd-ish stride coprime to n_slots, so
             // that the lanes of one wave hold tets that are far apart (no shared vertices)

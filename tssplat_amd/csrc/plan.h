@@ -166,6 +166,7 @@ struct Plan {
     int64_t total_slots = 0, total_tile_verts = 0;
     int32_t max_slots = 0, max_verts = 0, block_threads = 64, lds_bytes = 0, spt = kSlotsPerLane;
     int32_t n_planes = kPlanes;      // kPlanes, or kPlanesWeighted when an explicit operator was given
+    int32_t vert_stride = 64;        // gvid entries per tile (tile t's ids start at t * vert_stride = its TileDesc::vert_off)
     std::vector<float> op_diag;      // explicit operator only: L[e,e] per tet
     std::vector<float> op_w;         // explicit operator only: L[e, nbr[4e+k]] per tet face (0 on boundary faces)
 };
