@@ -508,7 +508,7 @@ def _run_rank(args, stdout_fd: int) -> None:
                 "launch": {"graph": "HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier.step)",
                            "eager": "eager: SmoothnessBarrierEnergy + backward() through torch.autograd",
                            "graph-autograd": "SmoothnessBarrierEnergy(graph=True) + backward(): HIP-graph replay behind an autograd node"}[launch_mode],
-                "schedule": "coefficients follow coeff_scheduler(it) and change every step (one 8-byte H2D refresh per replay)",
+                "schedule": "coefficients follow coeff_scheduler(it) and change every step (replays update them as kernel-node arguments, no device traffic)",
                 "energy_exchange": (f"per-step local energies into a ring of {reducer.window} device slots, one all-reduce per window "
                                     f"({reducer.collectives} collectives so far, backend {dist.get_backend()}, {dist.get_world_size()} rank(s))"
                                     if reducer is not None else "none (one rank, no process group)"),
