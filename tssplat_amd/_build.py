@@ -19,9 +19,9 @@ LIB = os.path.join(_HERE, "libtssplat_amd.so")
 _OBJ = os.path.join(_HERE, "_obj")
 ARCH = "gfx950"
 
-SOURCES = ["plan.cpp", "conflict_opt.cpp", "capi.cpp", "kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
+SOURCES = ["plan.cpp", "conflict_opt.cpp", "stream_plan.cpp", "stream_capi.cpp", "capi.cpp", "kernels.hip", "stream_kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
            "raster_capi.cpp", "raster_kernels.hip"]
-HEADERS = ["plan.h", "conflict_opt.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
+HEADERS = ["plan.h", "conflict_opt.h", "stream_plan.h", "stream_kernels.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]
 # -fno-slp-vectorize: SLP packs the 3x3 algebra into v_pk_*_f32, which runs at the scalar-fp32 rate on

@@ -52,6 +52,20 @@ class PlanInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class StreamPlanInfo(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_vertices", "n_tets", "n_components", "n_tubes", "total_slots", "total_bands", "total_pairs",
+                                         "total_chunks", "shared_vertex_copies", "finish_vertices", "device_bytes", "blob_bytes")] + \
+               [(k, C.c_int32) for k in ("max_vertex_slots", "max_bands", "band_slots", "lds_bytes")]
+
+    def as_dict(self) -> dict:
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class StreamTubeView(C.Structure):
+    _fields_ = [("n_bands", C.c_int32), ("n_vslots", C.c_int32), ("n_owned", C.c_int32), ("n_slots", C.c_int32),
+                ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_int64), ("slot_tet", C.POINTER(C.c_int32))]
+
+
 class TileView(C.Structure):
     _fields_ = [
         ("n_slots", C.c_int32), ("n_owned", C.c_int32), ("s_pad", C.c_int32), ("n_verts", C.c_int32),
@@ -97,6 +111,18 @@ SIGNATURES = {
                                         C.c_float, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
     "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    # streaming tiles (experimental)
+    "tsamd_stream_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "tsamd_stream_destroy": (None, [C.c_void_p]),
+    "tsamd_stream_info": (C.c_int, [C.c_void_p, C.POINTER(StreamPlanInfo)]),
+    "tsamd_stream_get_tube": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(StreamTubeView)]),
+    "tsamd_stream_get_finish_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)),
+                                                C.POINTER(C.POINTER(C.c_int32))]),
+    "tsamd_stream_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p]),
+    "tsamd_stream_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "tsamd_stream_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "tsamd_stream_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     # renderer slice
     "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "tsamd_rasterize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -43,6 +43,9 @@ struct EvalGraph;
 hipError_t eval_graph_create(const EvalArgs &a, EvalGraph **out);
 hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream);
 void eval_graph_destroy(EvalGraph *g);
+hipError_t launch_finish(const int32_t *fin_vid, const int32_t *fin_off, int64_t n_finish, const float *stage, float *grad,
+                         const float *grad_out, const double *partials, int64_t n_partials, float c1, float c2, float *energy,
+                         double *terms, hipStream_t stream);
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
 hipError_t launch_adam_uniform(float *p, const float *grad, float *g1, float *g2, int64_t n, float lr, float b1, float b2,

@@ -1267,6 +1267,37 @@ void eval_graph_destroy(EvalGraph *g)
     delete g;
 }
 
+// The finish launch on its own (shared-vertex sums in plan order + energy reduction), for the streaming-tile path.
+hipError_t launch_finish(const int32_t *fin_vid, const int32_t *fin_off, int64_t n_finish, const float *stage, float *grad,
+                         const float *grad_out, const double *partials, int64_t n_partials, float c1, float c2, float *energy,
+                         double *terms, hipStream_t stream)
+{
+    FinishArgs f;
+    f.fin_vid = fin_vid;
+    f.fin_off = fin_off;
+    f.fin_idx = nullptr;
+    f.n_finish = n_finish;
+    f.stage = stage;
+    f.grad = grad;
+    f.grad_out = grad_out;
+    f.partials = partials;
+    f.n_tiles = n_partials;
+    f.c1 = c1;
+    f.c2 = c2;
+    f.coef = nullptr;
+    f.energy = energy;
+    f.terms = terms;
+    if (n_finish > 0) {
+        hipLaunchKernelGGL(finish_kernel, dim3(1u + unsigned(grid_for(n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
+        return hipGetLastError();
+    }
+    if (energy) {
+        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
