@@ -64,11 +64,13 @@ int to_device(tsamd_stream *h, int device)
         return capi_fail(TSAMD_ERR_NO_DEVICE, "no HIP device is visible (this library has no CPU fallback)");
     if (device < 0) TSAMD_HIP(hipGetDevice(&device));
     if (device >= count) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    const tsamd::StreamPlan &P = h->plan;
+    if (tsamd::stream_lds_bytes(P.max_vslots, P.max_bands) > 160 * 1024)
+        return capi_fail(TSAMD_ERR_TILING, "a tube needs more than 160 KiB of LDS (vertex ring + band descriptors): use tsamd_create");
     DeviceGuard g;
     TSAMD_HIP(g.enter(device));
     h->device = device;
     h->host_only = false;
-    const tsamd::StreamPlan &P = h->plan;
     int rc;
     if ((rc = upload(h->d_tubes, P.tubes.data(), P.tubes.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(P.blob.data()), P.blob.size() * 4, h->device_bytes))) return rc;
@@ -79,7 +81,7 @@ int to_device(tsamd_stream *h, int device)
     if ((rc = upload(h->d_terms, nullptr, 2, h->device_bytes))) return rc;
     if ((rc = upload(h->d_energy_scratch, nullptr, 1, h->device_bytes))) return rc;
     TSAMD_HIP(hipMemset(h->d_terms, 0, 2 * sizeof(double)));
-    TSAMD_HIP(tsamd::configure_stream_kernels(tsamd::stream_lds_bytes(P.max_vslots)));
+    TSAMD_HIP(tsamd::configure_stream_kernels(tsamd::stream_lds_bytes(P.max_vslots, P.max_bands)));
     return TSAMD_OK;
 }
 
@@ -139,7 +141,7 @@ int tsamd_stream_info(const tsamd_stream *h, tsamd_stream_plan_info *out)
     out->max_vertex_slots = P.max_vslots;
     out->max_bands = P.max_bands;
     out->band_slots = tsamd::kBand;
-    out->lds_bytes = tsamd::stream_lds_bytes(P.max_vslots);
+    out->lds_bytes = tsamd::stream_lds_bytes(P.max_vslots, P.max_bands);
     return TSAMD_OK;
 }
 
@@ -184,7 +186,7 @@ int tsamd_stream_forward_backward(tsamd_stream *h, const float *x_dev, const flo
     a.fin_off = h->d_fin_off;
     a.n_tubes = int64_t(h->plan.tubes.size());
     a.n_finish = int64_t(h->plan.fin_vid.size());
-    a.lds_bytes = tsamd::stream_lds_bytes(h->plan.max_vslots);
+    a.lds_bytes = tsamd::stream_lds_bytes(h->plan.max_vslots, h->plan.max_bands);
     a.x = x_dev;
     a.grad_out = grad_out_dev;
     a.c1 = c1;

@@ -26,7 +26,7 @@ struct StreamEvalArgs {
     double *terms;                 // [2]
 };
 
-int32_t stream_lds_bytes(int32_t max_vslots);
+int32_t stream_lds_bytes(int32_t max_vslots, int32_t max_bands);
 hipError_t configure_stream_kernels(int lds_bytes);
 // ev: optional 3 events (before the tube kernel, between the kernels, after the finish kernel)
 hipError_t launch_stream_eval(const StreamEvalArgs &a, hipStream_t stream, hipEvent_t *ev = nullptr);

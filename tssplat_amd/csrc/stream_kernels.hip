@@ -140,6 +140,12 @@ struct StreamKernelArgs {
     int tubes_per_xcd;
 };
 
+// experiments: -DTSAMD_STREAM_SKIP=mask switches stage bodies off (bit 0: pass 1 compute, 1: pass 2, 2: pass 3, 3: vertex sums;
+// results are wrong while a bit is set) -- prices the stages.
+#ifndef TSAMD_STREAM_SKIP
+#define TSAMD_STREAM_SKIP 0
+#endif
+
 struct BandInfo {   // StreamBandDesc unpacked
     uint32_t planes_off, enter_off, pairs_off, chunks_off, n_slots, n_owned, n_enter, n_pairs;
 };
@@ -157,16 +163,24 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int tube = xcd * a.tubes_per_xcd + jb;
-    if (jb >= a.tubes_per_xcd || tube >= a.n_tubes || tube >= (xcd + 1) * a.tubes_per_xcd) return;
+    if (jb >= a.tubes_per_xcd || tube >= a.n_tubes) return;
     const StreamTubeDesc td = a.tubes[tube];
     const int tid = threadIdx.x, group = tid >> 8, lane = tid & (kGroup - 1);
     const int nb = td.n_bands;
     const uint32_t VR16 = 16u * uint32_t((td.n_vslots + 3) & ~3);
-    const uint32_t ACC_BASE = XS_BASE + VR16, SCAL_BASE = ACC_BASE + VR16, RED_BASE = SCAL_BASE + kScalRing * kBand * 4u;
+    const uint32_t ACC_BASE = XS_BASE + VR16, SCAL_BASE = ACC_BASE + VR16, RED_BASE = SCAL_BASE + kScalRing * kBand * 4u,
+                   DESC_BASE = RED_BASE + 64u;
     const auto g_blob = as_global(a.blob) + td.blob_off;
     const auto g_x = as_global(a.x);
-    auto band_desc = [&](int b) {   // (wave-uniform address: scalar loads)
-        const GLOBAL_AS uint32_t *w = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + size_t(b) * sizeof(StreamBandDesc));
+
+    // the tube's band descriptors -> LDS (every stage reads the descriptor of its band every step: an LDS broadcast read
+    // instead of a dependent scalar load from HBM at the head of the step)
+    for (int w = tid; w < nb * 6; w += 1024) lds_at<uint32_t>(DESC_BASE)[w] = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob)[w];
+    // the all-zero force records the incidence padding points at
+    if (tid < 2 * 12) lds_at<float>(D_BASE + uint32_t(tid / 12) * kDBandBytes + 48u * kBand)[tid % 12] = 0.f;
+    __syncthreads();
+    auto band_desc = [&](int b) {
+        const LDS_AS uint32_t *w = lds_at<const uint32_t>(DESC_BASE + uint32_t(b) * 24u);
         BandInfo d;
         d.planes_off = w[0];
         d.enter_off = w[1];
@@ -186,11 +200,11 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
     const bool factored = k_c1 != 0.f && __builtin_fabsf(ratio) <= 0x1p+40f;
     const float s_pen = factored ? ratio : k_c2, out_scale = factored ? k_c1 : 1.f, q_scale = factored ? 1.f : k_c1;
 
-    // the all-zero force records the incidence padding points at
-    if (tid < 2 * 12) lds_at<float>(D_BASE + uint32_t(tid / 12) * kDBandBytes + 48u * kBand)[tid % 12] = 0.f;
-
     float e_acc = 0.f;   // group 0: sum of penalties; group 1: sum of 1/2 |H|^2
     const int n_steps = nb + (WITH_GRAD ? kLagSum : kLagP2);
+    // Every group runs the same step loop (one barrier per step), from s = -2: the two leading steps only prefetch.  Each
+    // group keeps the global data of its NEXT band (or next two) in registers, requested a step (or two) ahead, so that no
+    // step starts with a dependent memory latency.
 
     if (group == 0) {
         // ---- stream + pass 1 ----
@@ -198,27 +212,42 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
         float c_dm[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) c_dm[c] = 0.f;
-        for (int s = -1; s < n_steps; ++s) {
+        uint32_t c_nslots = 0;
+        int32_t e1_slot = -1, e1_vid = 0;   // this lane's entering vertex of band s + 1 (its list entry was loaded a step ago)
+        for (int s = -2; s < n_steps; ++s) {
+            // (a) list entry of band s + 2
+            int32_t e2_slot = -1, e2_vid = 0;
+            if (s + 2 < nb) {
+                const BandInfo d2 = band_desc(s + 2);
+                if (uint32_t(lane) < d2.n_enter) {
+                    const v2u ev = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + d2.enter_off)[lane];
+                    e2_slot = int32_t(ev.x);
+                    e2_vid = int32_t(ev.y);
+                }
+            }
+            // (b) planes of band s + 1 and the position of this lane's entering vertex of band s + 1
             uint32_t n_lv01 = 0, n_lv23 = 0;
             float n_dm[9];
 #pragma unroll
             for (int c = 0; c < 9; ++c) n_dm[c] = 0.f;
-            const bool have_next = s + 1 < nb;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            const bool have_next = s + 1 >= 0 && s + 1 < nb;
             BandInfo dn = {};
-            int32_t en_slot = -1, en_vid = 0;
             if (have_next) {
                 dn = band_desc(s + 1);
                 n_lv01 = plane(dn, 0);
                 n_lv23 = plane(dn, 1);
 #pragma unroll
                 for (int c = 0; c < 9; ++c) n_dm[c] = planef(dn, 4 + c);
-                if (uint32_t(lane) < dn.n_enter) {
-                    const v2u ev = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + dn.enter_off)[lane];
-                    en_slot = int32_t(ev.x);
-                    en_vid = int32_t(ev.y);
+                if (e1_slot >= 0) {
+                    const size_t gv = size_t(e1_vid) * 3;
+                    px = g_x[gv];
+                    py = g_x[gv + 1];
+                    pz = g_x[gv + 2];
                 }
             }
-            if (s >= 0 && s < nb) {
+            // (c) pass 1 on band s (lanes beyond the band's slots have nothing to do: nobody reads their records)
+            if (!(TSAMD_STREAM_SKIP & 1) && s >= 0 && s < nb && uint32_t(lane) < c_nslots) {
                 float F[9];
                 slot_F(XS_BASE, c_lv01, c_lv23, c_dm, F);
                 float scal = 0.f;
@@ -239,14 +268,13 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
                 store_rec(rec_addr(F_BASE + uint32_t(s & 3) * kBandBytes, uint32_t(lane)), F);
                 if (WITH_GRAD) lds_at<float>(SCAL_BASE + uint32_t(s % kScalRing) * kBand * 4u)[lane] = scal;
             }
+            // (d) entering vertices of band s + 1: position -> ring slot, accumulator = 0 (visible after this step's barrier)
             if (have_next) {
-                // entering vertices of band s+1: position -> ring slot, accumulator = 0 (visible after this step's barrier)
-                if (en_slot >= 0) {
-                    const size_t gv = size_t(en_vid) * 3;
-                    *lds_at<v4f>(XS_BASE + 16u * uint32_t(en_slot)) = v4f{g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f};
-                    *lds_at<v4f>(ACC_BASE + 16u * uint32_t(en_slot)) = v4f{0.f, 0.f, 0.f, 0.f};
+                if (e1_slot >= 0) {
+                    *lds_at<v4f>(XS_BASE + 16u * uint32_t(e1_slot)) = v4f{px, py, pz, 0.f};
+                    *lds_at<v4f>(ACC_BASE + 16u * uint32_t(e1_slot)) = v4f{0.f, 0.f, 0.f, 0.f};
                 }
-                for (int q = lane + kGroup; q < int(dn.n_enter); q += kGroup) {   // more entering vertices than lanes (first band of a tube)
+                for (int q = lane + kGroup; q < int(dn.n_enter); q += kGroup) {   // more entering vertices than lanes (rare)
                     const v2u ev = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + dn.enter_off)[q];
                     const size_t gv = size_t(ev.y) * 3;
                     *lds_at<v4f>(XS_BASE + 16u * ev.x) = v4f{g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f};
@@ -255,17 +283,27 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
             }
             c_lv01 = n_lv01;
             c_lv23 = n_lv23;
+            c_nslots = have_next ? dn.n_slots : 0u;
 #pragma unroll
             for (int c = 0; c < 9; ++c) c_dm[c] = n_dm[c];
+            e1_slot = e2_slot;
+            e1_vid = e2_vid;
             __syncthreads();
         }
     } else if (group == 1) {
         // ---- pass 2 on band s - 2 ----
-        for (int s = -1; s < n_steps; ++s) {
+        uint32_t c_n01 = 0, c_n23 = 0, c_nslots = 0;
+        for (int s = -2; s < n_steps; ++s) {
             const int b = s - kLagP2;
-            if (b >= 0 && b < nb) {
-                const BandInfo d = band_desc(b);
-                const uint32_t n01 = plane(d, 2), n23 = plane(d, 3);
+            uint32_t n_n01 = 0, n_n23 = 0, n_nslots = 0;
+            if (b + 1 >= 0 && b + 1 < nb) {
+                const BandInfo dn = band_desc(b + 1);
+                n_n01 = plane(dn, 2);
+                n_n23 = plane(dn, 3);
+                n_nslots = dn.n_slots;
+            }
+            if (!(TSAMD_STREAM_SKIP & 2) && b >= 0 && b < nb && uint32_t(lane) < c_nslots) {
+                const uint32_t n01 = c_n01, n23 = c_n23;
                 float H[9];
                 if (n01 & kOwnedBit) {
                     const uint32_t t0 = nbr_addr(F_BASE, uint32_t(b), n01 & 0x3ffu), t1 = nbr_addr(F_BASE, uint32_t(b), (n01 >> 16) & 0x3ffu),
@@ -292,18 +330,33 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
                 }
                 if (WITH_GRAD) store_rec(rec_addr(H_BASE + uint32_t(b & 3) * kBandBytes, uint32_t(lane)), H);
             }
+            c_n01 = n_n01;
+            c_n23 = n_n23;
+            c_nslots = n_nslots;
             __syncthreads();
         }
     } else if (group == 2) {
         // ---- pass 3 on band s - 4 ----
-        for (int s = -1; s < n_steps; ++s) {
-            const int b = s - kLagP3;
-            if (WITH_GRAD && b >= 0 && b < nb) {
-                const BandInfo d = band_desc(b);
-                const uint32_t n01 = plane(d, 2), n23 = plane(d, 3);
-                float dm[9];
+        uint32_t c_pl[4] = {0, 0, 0, 0}, c_nslots = 0;
+        float c_dm[9];
 #pragma unroll
-                for (int c = 0; c < 9; ++c) dm[c] = planef(d, 4 + c);
+        for (int c = 0; c < 9; ++c) c_dm[c] = 0.f;
+        for (int s = -2; s < n_steps; ++s) {
+            const int b = s - kLagP3;
+            uint32_t n_pl[4] = {0, 0, 0, 0}, n_nslots = 0;
+            float n_dm[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) n_dm[c] = 0.f;
+            if (WITH_GRAD && b + 1 >= 0 && b + 1 < nb) {
+                const BandInfo dn = band_desc(b + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) n_pl[q] = plane(dn, q);
+#pragma unroll
+                for (int c = 0; c < 9; ++c) n_dm[c] = planef(dn, 4 + c);
+                n_nslots = dn.n_slots;
+            }
+            if (WITH_GRAD && !(TSAMD_STREAM_SKIP & 4) && b >= 0 && b < nb && uint32_t(lane) < c_nslots) {
+                const uint32_t n01 = c_pl[2], n23 = c_pl[3];
                 const float scal = lds_at<const float>(SCAL_BASE + uint32_t(b % kScalRing) * kBand * 4u)[lane];
                 const uint32_t t0 = nbr_addr(H_BASE, uint32_t(b), n01 & 0x3ffu), t1 = nbr_addr(H_BASE, uint32_t(b), (n01 >> 16) & 0x3ffu),
                                t2 = nbr_addr(H_BASE, uint32_t(b), n23 & 0x3ffu), t3 = nbr_addr(H_BASE, uint32_t(b), (n23 >> 16) & 0x3ffu);
@@ -321,9 +374,8 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
                     for (int c = 0; c < 9; ++c) P[c] *= q_scale;
                 }
                 if (scal != 0.f) {   // inverted owned tet: F again, from the position ring
-                    const uint32_t w0 = plane(d, 0), w1 = plane(d, 1);
                     float F[9], C[9];
-                    slot_F(XS_BASE, w0, w1, dm, F);
+                    slot_F(XS_BASE, c_pl[0], c_pl[1], c_dm, F);
                     cof3(F, C);
 #pragma unroll
                     for (int c = 0; c < 9; ++c) P[c] += scal * C[c];
@@ -332,12 +384,17 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) D[3 * k + i] = P[3 * i + 0] * dm[3 * k + 0] + P[3 * i + 1] * dm[3 * k + 1] + P[3 * i + 2] * dm[3 * k + 2];
+                    for (int i = 0; i < 3; ++i) D[3 * k + i] = P[3 * i + 0] * c_dm[3 * k + 0] + P[3 * i + 1] * c_dm[3 * k + 1] + P[3 * i + 2] * c_dm[3 * k + 2];
                 const uint32_t r = D_BASE + uint32_t(b & 1) * kDBandBytes + 48u * uint32_t(lane);
                 *lds_at<v4f>(r) = v4f{-(D[0] + D[3] + D[6]), -(D[1] + D[4] + D[7]), -(D[2] + D[5] + D[8]), D[0]};
                 *lds_at<v4f>(r + 16) = v4f{D[1], D[2], D[3], D[4]};
                 *lds_at<v4f>(r + 32) = v4f{D[5], D[6], D[7], D[8]};
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c_pl[q] = n_pl[q];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) c_dm[c] = n_dm[c];
+            c_nslots = n_nslots;
             __syncthreads();
         }
     } else {
@@ -345,29 +402,49 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
         const float gscale = (a.grad_out ? *as_global(a.grad_out) : 1.f) * out_scale;
         const auto g_grad = as_global(a.grad);
         const auto g_stage = as_global(a.stage);
-        for (int s = -1; s < n_steps; ++s) {
+        // this lane's pair of band b (p0) with its first two chunks (ch0), of band b + 1 (p1: its chunks are requested now),
+        // of band b + 2 (requested now)
+        uint32_t p0[3] = {0, 0, 0}, p1[3] = {0, 0, 0};
+        v2u ch0[2] = {v2u{0, 0}, v2u{0, 0}};
+        bool has0 = false, has1 = false;
+        constexpr uint32_t kPadChunk = uint32_t(kBand << 2) * 0x10001u;
+        for (int s = -2; s < n_steps; ++s) {
             const int b = s - kLagSum;
-            if (WITH_GRAD && b >= 0 && b < nb) {
+            uint32_t p2[3] = {0, 0, 0};
+            bool has2 = false;
+            v2u ch1[2] = {v2u{kPadChunk, kPadChunk}, v2u{kPadChunk, kPadChunk}};
+            if (WITH_GRAD && b + 2 >= 0 && b + 2 < nb) {
+                const BandInfo d2 = band_desc(b + 2);
+                if (uint32_t(lane) < d2.n_pairs) {
+                    const GLOBAL_AS uint32_t *pr = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + d2.pairs_off) + 3 * size_t(lane);
+                    p2[0] = pr[0];
+                    p2[1] = pr[1];
+                    p2[2] = pr[2];
+                    has2 = true;
+                }
+            }
+            if (WITH_GRAD && has1) {
+                const BandInfo d1 = band_desc(b + 1);
+                const uint32_t nch = (p1[0] >> 16) & 0x3fffu;
+                const GLOBAL_AS v2u *ch = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + d1.chunks_off) + p1[1];
+                ch1[0] = ch[0];                       // (every pair has at least one chunk)
+                if (nch > 1) ch1[1] = ch[1];
+            }
+            if (WITH_GRAD && !(TSAMD_STREAM_SKIP & 8) && b >= 0 && b < nb) {
                 const BandInfo d = band_desc(b);
                 const uint32_t dbase = D_BASE + uint32_t(b & 1) * kDBandBytes;
-                for (int p = lane; p < int(d.n_pairs); p += kGroup) {
-                    const GLOBAL_AS uint32_t *pr = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + d.pairs_off) + 3 * size_t(p);
-                    const uint32_t w0 = pr[0], first = pr[1];
-                    const int32_t out_row = int32_t(pr[2]);
-                    const uint32_t vslot = w0 & 0xffffu, flags = w0 >> 16, nch = flags & 0x3fffu;
-                    const GLOBAL_AS v2u *ch = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + d.chunks_off) + first;
-                    float gx = 0.f, gy = 0.f, gz = 0.f;
-                    for (uint32_t c = 0; c < nch; ++c) {
-                        const v2u wv = ch[c];
-                        const uint32_t ent[4] = {wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16};
+                auto gather4 = [&](const v2u wv, float &gx, float &gy, float &gz) {
+                    const uint32_t ent[4] = {wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const LDS_AS float *f = lds_at<const float>(dbase + ent[q] * 12u);
-                            gx += f[0];
-                            gy += f[1];
-                            gz += f[2];
-                        }
+                    for (int q = 0; q < 4; ++q) {
+                        const LDS_AS float *f = lds_at<const float>(dbase + ent[q] * 12u);
+                        gx += f[0];
+                        gy += f[1];
+                        gz += f[2];
                     }
+                };
+                auto finish_pair = [&](uint32_t w0, int32_t out_row, float gx, float gy, float gz) {
+                    const uint32_t vslot = w0 & 0xffffu, flags = w0 >> 16;
                     const uint32_t aa = ACC_BASE + 16u * vslot;
                     v4f acc = *lds_at<v4f>(aa);
                     acc.x += gx;
@@ -383,8 +460,38 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
                     } else {
                         *lds_at<v4f>(aa) = acc;
                     }
+                };
+                if (has0) {
+                    const uint32_t nch = (p0[0] >> 16) & 0x3fffu;
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    gather4(ch0[0], gx, gy, gz);
+                    gather4(ch0[1], gx, gy, gz);
+                    if (nch > 2) {   // longer lists: the remaining chunks straight from memory
+                        const GLOBAL_AS v2u *ch = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + d.chunks_off) + p0[1];
+                        for (uint32_t c = 2; c < nch; ++c) gather4(ch[c], gx, gy, gz);
+                    }
+                    finish_pair(p0[0], int32_t(p0[2]), gx, gy, gz);
+                }
+                for (int p = lane + kGroup; p < int(d.n_pairs); p += kGroup) {   // more pairs than lanes (rare)
+                    const GLOBAL_AS uint32_t *pr = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + d.pairs_off) + 3 * size_t(p);
+                    const uint32_t w0 = pr[0], first = pr[1];
+                    const int32_t out_row = int32_t(pr[2]);
+                    const uint32_t nch = (w0 >> 16) & 0x3fffu;
+                    const GLOBAL_AS v2u *ch = reinterpret_cast<const GLOBAL_AS v2u *>(g_blob + d.chunks_off) + first;
+                    float gx = 0.f, gy = 0.f, gz = 0.f;
+                    for (uint32_t c = 0; c < nch; ++c) gather4(ch[c], gx, gy, gz);
+                    finish_pair(w0, out_row, gx, gy, gz);
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                p0[q] = p1[q];
+                p1[q] = p2[q];
+            }
+            ch0[0] = ch1[0];
+            ch0[1] = ch1[1];
+            has0 = has1;
+            has1 = has2;
             __syncthreads();
         }
     }
@@ -404,10 +511,10 @@ __global__ __launch_bounds__(1024, 4) void stream_tube_kernel(const StreamKernel
 
 }  // namespace
 
-int32_t stream_lds_bytes(int32_t max_vslots)
+int32_t stream_lds_bytes(int32_t max_vslots, int32_t max_bands)
 {
     const uint32_t vr16 = 16u * uint32_t((max_vslots + 3) & ~3);
-    return int32_t(XS_BASE + 2 * vr16 + kScalRing * kBand * 4u + 256u);
+    return int32_t(XS_BASE + 2 * vr16 + kScalRing * kBand * 4u + 64u + 24u * uint32_t(max_bands) + 16u);
 }
 
 hipError_t configure_stream_kernels(int lds_bytes)
