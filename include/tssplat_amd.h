@@ -273,7 +273,8 @@ int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev
  * into a few tubes, each swept level by level (breadth-first over face adjacency: neighbours are within +-1 level) with
  * a rolling window of band records in LDS and four wave groups running four stages on four bands per barrier interval
  * (tssplat_amd/csrc/stream_plan.h).  1.08 instead of 1.28 tile slots per tet on the headline scene.  Its own handle
- * type; tsamd_create / TetSpheres remain the product path until this one has measured faster.  Built-in uniform
+ * type; tsamd_create / TetSpheres remain the product path: measured on the headline scene this path takes 0.73 ms
+ * against 0.43 ms (profiles/r03_experiments.md).  Built-in uniform
  * operator only.  TSAMD_ERR_TILING = a component cannot be cut into tubes whose widest level fits a band: use tsamd_create.
  */
 typedef struct tsamd_stream tsamd_stream;
