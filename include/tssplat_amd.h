@@ -318,7 +318,8 @@ int tsamd_stream_read_energy_terms(tsamd_stream *h, void *stream, double *terms_
  * the current HIP device is used.  pos_clip_dev: [batch, n_vertices, 4] f32; tri_dev: [n_triangles, 3] i32;
  * rast: [batch, height, width, 4] f32; attr_dev: [attr_batch (1 or batch), n_vertices, n_channels] f32.
  */
-int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int32_t height, int32_t width);
+/* workspace: one 64-bit depth key per pixel and one 16-byte snapped vertex per (view, vertex) */
+int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width);
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
                     int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *stream);
 int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,

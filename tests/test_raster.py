@@ -107,8 +107,8 @@ def test_interpolate_backward_is_the_adjoint():
 
 def test_c_abi_rejects_bad_arguments():
     lib = _capi.load()
-    assert lib.tsamd_rasterize_workspace_bytes(8, 512, 512) == 8 * 512 * 512 * 8
-    assert lib.tsamd_rasterize_workspace_bytes(-1, 4, 4) == -1
+    assert lib.tsamd_rasterize_workspace_bytes(8, 1000, 512, 512) == 8 * 512 * 512 * 8 + 8 * 1000 * 16
+    assert lib.tsamd_rasterize_workspace_bytes(-1, 3, 4, 4) == -1
     assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None) == 1          # null workspace / output
     assert b"null" in lib.tsamd_last_error()
     assert lib.tsamd_rasterize(None, 1, 3, None, 1, 20000, 4, None, None, None) == 1

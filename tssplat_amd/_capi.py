@@ -124,7 +124,7 @@ SIGNATURES = {
     "tsamd_stream_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_stream_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     # renderer slice
-    "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tsamd_rasterize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "tsamd_interpolate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -7,7 +7,7 @@
 
 namespace tsamd {
 
-// workspace: batch * height * width 64-bit depth keys
+// workspace: batch * height * width 64-bit depth keys, then batch * n_vertices 16-byte snapped vertices
 hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vertices, const int32_t *tri, int64_t n_tri, int height, int width,
                             void *workspace, float *rast, hipStream_t stream);
 hipError_t launch_interpolate(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,

@@ -20,10 +20,10 @@ int check_image(int64_t batch, int32_t height, int32_t width)
 
 extern "C" {
 
-int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int32_t height, int32_t width)
+int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width)
 {
-    if (batch < 0 || height < 0 || width < 0) return -1;
-    return batch * int64_t(height) * int64_t(width) * 8;
+    if (batch < 0 || n_vertices < 0 || height < 0 || width < 0) return -1;
+    return ((batch * int64_t(height) * int64_t(width) + 1) & ~int64_t(1)) * 8 + batch * n_vertices * 16;   // depth keys (padded to 16 B) + snapped vertices
 }
 
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles, int32_t height,

@@ -6,8 +6,9 @@
 // algorithm with every open choice fixed there); coverage and the depth test repeat its float64 / integer operations
 // one by one, which is what makes the triangle ids bit-exact against it.
 //
-//   rasterize_bin_kernel   one lane per (view, triangle): snap, set up the three integer edge functions, walk the
-//                          pixel centres of the bounding box, 64-bit atomicMin of (depth32 << 32 | triangle) per pixel
+//   rasterize_snap_kernel  one lane per (view, vertex): window coordinates in 1/256 pixel + z/w in float64, 16 B
+//   rasterize_bin_kernel   one lane per (view, triangle): set up the three integer edge functions, walk the pixel
+//                          centres of the bounding box, 64-bit atomicMin of (depth32 << 32 | triangle) per pixel
 //   rasterize_resolve_kernel  one lane per pixel: winning triangle -> (u, v, z/w, id + 1)
 //   interpolate_kernel / interpolate_backward_kernel  one lane per pixel
 //
@@ -25,33 +26,43 @@ constexpr long long kSub = 1ll << kSubBits;
 constexpr long long kCoordLimit = 1ll << 22;
 constexpr unsigned long long kNoFragment = 0xFFFFFFFFFFFFFFFFull;
 
-struct Snapped {
-    long long x, y;
+// One snapped vertex of one view, 16 bytes: window coordinates in 1/256 pixel (|x|, |y| <= 2^22) and z/w in float64.
+// x == kDropped: the vertex is not finite, behind the eye (w <= 0) or out of the coordinate range -- its triangles are dropped.
+struct SnapRec {
+    int32_t x, y;
     double zw;
-    bool ok;
 };
+static_assert(sizeof(SnapRec) == 16, "SnapRec is loaded as one 16-byte word");
+constexpr int32_t kDropped = INT32_MIN;
 
-// oracle/raster_oracle.py::snap_vertices, operation by operation (explicitly rounded double intrinsics: no contraction)
-__device__ __forceinline__ Snapped snap(const float4 p, double width, double height)
+// oracle/raster_oracle.py::snap_vertices, operation by operation (explicitly rounded double intrinsics: no contraction).
+// One lane per (view, vertex): a vertex is snapped once per view, not once per triangle that uses it (six on a closed
+// surface) -- the three float64 divisions are the expensive part of the triangle set-up.
+__global__ __launch_bounds__(256) void rasterize_snap_kernel(const float4 *pos, int64_t n, double width, double height, SnapRec *out)
 {
-    Snapped s;
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const float4 p = pos[gid];
     const double x = double(p.x), y = double(p.y), z = double(p.z), w = double(p.w);
-    s.ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w) && p.w > 0.f;
-    const double ws = s.ok ? w : 1.0;
+    bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w) && p.w > 0.f;
+    const double ws = ok ? w : 1.0;
     const double xs = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(x, ws), 0.5), 0.5), width);
     const double ys = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(y, ws), 0.5), 0.5), height);
     const double X = floor(__dadd_rn(__dmul_rn(xs, double(kSub)), 0.5));
     const double Y = floor(__dadd_rn(__dmul_rn(ys, double(kSub)), 0.5));
-    s.ok = s.ok && fabs(X) <= double(kCoordLimit) && fabs(Y) <= double(kCoordLimit);
-    s.x = s.ok ? (long long)X : 0;
-    s.y = s.ok ? (long long)Y : 0;
-    s.zw = s.ok ? __ddiv_rn(z, ws) : 0.0;
-    return s;
+    ok = ok && fabs(X) <= double(kCoordLimit) && fabs(Y) <= double(kCoordLimit);
+    SnapRec r;
+    r.x = ok ? int32_t(X) : kDropped;
+    r.y = ok ? int32_t(Y) : 0;
+    r.zw = ok ? __ddiv_rn(z, ws) : 0.0;
+    out[gid] = r;
 }
 
-__device__ __forceinline__ bool top_left(long long dx, long long dy) { return dy < 0 || (dy == 0 && dx < 0); }
+__device__ __forceinline__ bool top_left(int32_t dx, int32_t dy) { return dy < 0 || (dy == 0 && dx < 0); }
 
-__global__ __launch_bounds__(256) void rasterize_bin_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
+// experiments (results wrong / slower): -DTSAMD_RASTER_NO_ATOMIC prices the depth-key atomics, -DTSAMD_RASTER_NO_FILTER the
+// read-before-atomic filter
+__global__ __launch_bounds__(256) void rasterize_bin_kernel(const SnapRec *snapped, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
                                                             int64_t batch, int height, int width, unsigned long long *keys)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -59,36 +70,42 @@ __global__ __launch_bounds__(256) void rasterize_bin_kernel(const float4 *pos, c
     const int64_t b = gid / n_tri, t = gid - b * n_tri;
     const int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
     if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) return;
-    const float4 *pv = pos + b * n_vertices;
-    const Snapped s0 = snap(pv[i0], double(width), double(height));
-    Snapped s1 = snap(pv[i1], double(width), double(height)), s2 = snap(pv[i2], double(width), double(height));
-    if (!(s0.ok && s1.ok && s2.ok)) return;
-    const long long area = (s1.x - s0.x) * (s2.y - s0.y) - (s1.y - s0.y) * (s2.x - s0.x);
+    const SnapRec *sv = snapped + b * n_vertices;
+    const SnapRec s0 = sv[i0];
+    SnapRec s1 = sv[i1], s2 = sv[i2];
+    if (s0.x == kDropped || s1.x == kDropped || s2.x == kDropped) return;
+    const long long area = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s1.y - s0.y) * (s2.x - s0.x);
     if (area == 0) return;
     if (area < 0) {   // orient counter-clockwise
-        const Snapped tmp = s1;
+        const SnapRec tmp = s1;
         s1 = s2;
         s2 = tmp;
     }
-    const long long minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
-    const long long miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
+    const int32_t minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
+    const int32_t miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
     // pixel i has its centre at i * 256 + 128; >> is an arithmetic shift (floor) on negative values
-    const long long px0 = max(0ll, (minx - kSub / 2 + kSub - 1) >> kSubBits), px1 = min((long long)width - 1, (maxx - kSub / 2) >> kSubBits);
-    const long long py0 = max(0ll, (miny - kSub / 2 + kSub - 1) >> kSubBits), py1 = min((long long)height - 1, (maxy - kSub / 2) >> kSubBits);
-    if (px0 > px1 || py0 > py1) return;
+    const int32_t hs = int32_t(kSub / 2);
+    const int32_t px0 = max(0, (minx - hs + int32_t(kSub) - 1) >> kSubBits), px1 = min(width - 1, (maxx - hs) >> kSubBits);
+    const int32_t py0 = max(0, (miny - hs + int32_t(kSub) - 1) >> kSubBits), py1 = min(height - 1, (maxy - hs) >> kSubBits);
+    if (px0 > px1 || py0 > py1) return;   // no pixel centre inside the bounding box: most triangles of a dense surface end here
     // E_k = edge function of the edge opposite vertex k, >= 0 inside; d/dx = -(dy) * 256 per pixel, d/dy = dx * 256
-    const long long dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
+    const int32_t dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
     const bool tl0 = top_left(dx0, dy0), tl1 = top_left(dx1, dy1), tl2 = top_left(dx2, dy2);
-    const long long cx0 = px0 * kSub + kSub / 2, cy0 = py0 * kSub + kSub / 2;
-    long long r0 = dx0 * (cy0 - s1.y) - dy0 * (cx0 - s1.x);
-    long long r1 = dx1 * (cy0 - s2.y) - dy1 * (cx0 - s2.x);
-    long long r2 = dx2 * (cy0 - s0.y) - dy2 * (cx0 - s0.x);
+    const int32_t cx0 = px0 * int32_t(kSub) + hs, cy0 = py0 * int32_t(kSub) + hs;
+    long long r0 = (long long)dx0 * (cy0 - s1.y) - (long long)dy0 * (cx0 - s1.x);
+    long long r1 = (long long)dx1 * (cy0 - s2.y) - (long long)dy1 * (cx0 - s2.x);
+    long long r2 = (long long)dx2 * (cy0 - s0.y) - (long long)dy2 * (cx0 - s0.x);
+    const long long sx0 = (long long)dy0 * kSub, sx1 = (long long)dy1 * kSub, sx2 = (long long)dy2 * kSub;
+    const long long sy0 = (long long)dx0 * kSub, sy1 = (long long)dx1 * kSub, sy2 = (long long)dx2 * kSub;
     unsigned long long *kb = keys + size_t(b) * size_t(height) * size_t(width);
-    for (long long py = py0; py <= py1; ++py) {
+    for (int32_t py = py0; py <= py1; ++py) {
         long long e0 = r0, e1 = r1, e2 = r2;
-        for (long long px = px0; px <= px1; ++px) {
+        for (int32_t px = px0; px <= px1; ++px) {
             const bool in = (e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2));
             if (in) {
+                // z/w by the integer edge functions as weights: oracle/raster_oracle.py::rasterize_ids, operation by operation
+                // (a depth plane set up per triangle was measured slower here: 2.10 vs 1.86 ms, most triangles of the scene
+                // produce at most one fragment and the two divisions of the set-up are paid by every triangle with a bounding box)
                 const double a = double((e0 + e1) + e2);
                 const double num = __dadd_rn(__dadd_rn(__dmul_rn(double(e0), s0.zw), __dmul_rn(double(e1), s1.zw)), __dmul_rn(double(e2), s2.zw));
                 const double zw = __ddiv_rn(num, a);
@@ -96,16 +113,26 @@ __global__ __launch_bounds__(256) void rasterize_bin_kernel(const float4 *pos, c
                     double q = floor(__dmul_rn(__dadd_rn(zw, 1.0), 2147483648.0));
                     q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
                     const unsigned long long key = ((unsigned long long)q << 32) | (unsigned long long)t;
-                    atomicMin(kb + size_t(py) * size_t(width) + size_t(px), key);
+                    unsigned long long *slot = kb + size_t(py) * size_t(width) + size_t(px);
+#if defined(TSAMD_RASTER_NO_ATOMIC)
+                    if (key == 1) *slot = key;
+#elif defined(TSAMD_RASTER_NO_FILTER)
+                    atomicMin(slot, key);
+#else
+                    // the key only ever decreases, so any value read earlier is an upper bound of the current one: a
+                    // fragment that does not beat it cannot win and skips the device-scope atomic (most do: a pixel of a
+                    // scene with depth complexity d sees ~ln d improvements)
+                    if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);
+#endif
                 }
             }
-            e0 -= dy0 * kSub;
-            e1 -= dy1 * kSub;
-            e2 -= dy2 * kSub;
+            e0 -= sx0;
+            e1 -= sx1;
+            e2 -= sx2;
         }
-        r0 += dx0 * kSub;
-        r1 += dx1 * kSub;
-        r2 += dx2 * kSub;
+        r0 += sy0;
+        r1 += sy1;
+        r2 += sy2;
     }
 }
 
@@ -202,11 +229,15 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
     const int64_t pixels = batch * int64_t(height) * width;
     if (pixels <= 0) return hipSuccess;
     unsigned long long *keys = static_cast<unsigned long long *>(workspace);
+    SnapRec *snapped = reinterpret_cast<SnapRec *>(keys + ((size_t(pixels) + 1) & ~size_t(1)));   // 16-byte aligned
     hipError_t e = hipMemsetAsync(keys, 0xFF, size_t(pixels) * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    if (batch * n_tri > 0) {
-        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(blocks_for(batch * n_tri)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
-                           n_vertices, n_tri, batch, height, width, keys);
+    if (batch * n_tri > 0 && batch * n_vertices > 0) {
+        hipLaunchKernelGGL(rasterize_snap_kernel, dim3(blocks_for(batch * n_vertices)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip),
+                           batch * n_vertices, double(width), double(height), snapped);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(blocks_for(batch * n_tri)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri, batch, height,
+                           width, keys);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,

@@ -32,14 +32,14 @@ _lib = _capi.load()
 
 
 class RasterizeCudaContext:
-    """``dr.RasterizeCudaContext()`` (mesh_rasterizer.py:34): holds the depth-key workspace between calls."""
+    """``dr.RasterizeCudaContext()`` (mesh_rasterizer.py:34): holds the workspace (depth keys, snapped vertices) between calls."""
 
     def __init__(self, device=None):
         self.device = None if device is None else torch.device(device)
         self._ws = None
 
-    def workspace(self, batch: int, height: int, width: int, device: torch.device) -> torch.Tensor:
-        need = int(_lib.tsamd_rasterize_workspace_bytes(batch, height, width))
+    def workspace(self, batch: int, n_vertices: int, height: int, width: int, device: torch.device) -> torch.Tensor:
+        need = int(_lib.tsamd_rasterize_workspace_bytes(batch, n_vertices, height, width))
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=device)
         return self._ws
@@ -77,7 +77,7 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
     height, width = int(resolution[0]), int(resolution[1])
     B, V = int(pos.shape[0]), int(pos.shape[1])
     rast = torch.empty((B, height, width, 4), dtype=torch.float32, device=pos.device)
-    ws = glctx.workspace(B, height, width, pos.device)
+    ws = glctx.workspace(B, V, height, width, pos.device)
     with _device_ctx(pos.device):
         _capi.check(_lib.tsamd_rasterize(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), height, width, ws.data_ptr(),
                                          rast.data_ptr(), _stream_ptr(pos.device)))
