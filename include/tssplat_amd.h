@@ -306,15 +306,16 @@ int tsamd_stream_get_timing(tsamd_stream *h, double *tube_kernel_ms, double *fin
 int tsamd_stream_read_energy_terms(tsamd_stream *h, void *stream, double *terms_host2);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Renderer slice (first slice): the two nvdiffrast operators the reference's renderer calls,
+ * Renderer slice: the nvdiffrast operators the reference's renderer calls,
  *   tsamd_rasterize            <- dr.rasterize(ctx, pos_clip, tri, resolution=[H, W], grad_db=False)[0]   renderers/mesh_rasterizer.py:103
  *   tsamd_interpolate          <- dr.interpolate(attr, rast, tri)[0]                                     renderers/mesh_rasterizer.py:117,145,153
  *   tsamd_interpolate_backward <- the backward of the latter w.r.t. attr and rast's (u, v)
+ *   tsamd_rasterize_backward, tsamd_antialias* (below) <- the backward of dr.rasterize, dr.antialias and its backward   :103,107,128
  * nvdiffrast is a separate library (not vendored by the reference, version unpinned): the semantics implemented are a
  * restatement of its published algorithm, fixed in every detail by oracle/raster_oracle.py -- clip-space input, OpenGL
  * conventions (row 0 = bottom), no culling, nearest depth, output (u, v, z/w, triangle_id + 1), 0 = background.  PARITY
- * UNPINNED (no nvdiffrast here).  Not in this slice: antialias, the (u, v) -> position gradient of rasterize, polygon
- * clipping (a triangle with a vertex at w <= 0 is dropped), depth peeling, `ranges`.  Stateless: the caller owns all buffers and
+ * UNPINNED (no nvdiffrast here).  Not offered: polygon clipping (a triangle with a vertex at w <= 0 is dropped), depth
+ * peeling, `ranges`, image-space derivatives (grad_db).  Stateless: the caller owns all buffers and
  * the current HIP device is used.  pos_clip_dev: [batch, n_vertices, 4] f32; tri_dev: [n_triangles, 3] i32;
  * rast: [batch, height, width, 4] f32; attr_dev: [attr_batch (1 or batch), n_vertices, n_channels] f32.
  */
@@ -329,6 +330,30 @@ int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_verti
 int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
                                const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
                                float *grad_attr_dev, float *grad_rast_dev, void *stream);
+
+/* Gradient of tsamd_rasterize w.r.t. pos_clip from the gradient of its (u, v) outputs (what flows back from
+ * tsamd_interpolate_backward's grad_rast; z/w and the id carry none).  grad_pos_dev [batch, n_vertices, 4] is zero-filled and
+ * accumulated by the call.  <- the backward of dr.rasterize(..., grad_db=False), renderers/mesh_rasterizer.py:103 */
+int tsamd_rasterize_backward(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
+                             int32_t height, int32_t width, const float *rast_dev, const float *grad_rast_dev, float *grad_pos_dev, void *stream);
+
+/* tsamd_antialias <- dr.antialias(color, rast, pos_clip, tri, topology_hash=None, pos_gradient_boost=1.0)   renderers/mesh_rasterizer.py:107,128
+ * -- the only differentiable path from the alpha image to the geometry.  Every pair of adjacent pixels with different
+ * triangle ids is analysed: the closer triangle's silhouette edge that passes between the two pixel centres blends the two
+ * colours by the position of the crossing (specification: oracle/raster_oracle.py; PARITY UNPINNED like the rest of the slice).
+ * edge_partner_dev [3 * n_triangles] i32 is the topology table (nvdiffrast's topology hash): built once per triangle list by
+ * tsamd_antialias_topology with a workspace of tsamd_antialias_topology_workspace_bytes(n_triangles).
+ * color_dev / out_dev / grad_*: [batch, height, width, n_channels] f32.  The backward recomputes the analysis (no state is
+ * kept between the calls); grad_color_dev and grad_pos_dev ([batch, n_vertices, 4], zero-filled first) may each be NULL. */
+int64_t tsamd_antialias_topology_workspace_bytes(int64_t n_triangles);
+int tsamd_antialias_topology(const int32_t *tri_dev, int64_t n_triangles, void *workspace_dev, int32_t *edge_partner_dev, void *stream);
+int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
+                    int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
+                    void *stream);
+int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev,
+                             const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+                             int32_t n_channels, const float *grad_out_dev, float pos_gradient_boost, float *grad_color_dev, float *grad_pos_dev,
+                             void *stream);
 
 #ifdef __cplusplus
 }

@@ -194,6 +194,205 @@ def interpolate_backward(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray, gr
     return grad_attr, grad_rast
 
 
+def rasterize_backward(pos_clip: np.ndarray, tri: np.ndarray, rast: np.ndarray, grad_rast: np.ndarray) -> np.ndarray:
+    """Gradient of ``rasterize`` w.r.t. the clip-space positions, from the gradient of its ``(u, v)`` outputs (the z/w and
+    id channels carry none, as in nvdiffrast; the clamps of ``resolve`` are treated as inactive).  ``[B, V, 4]`` float64."""
+    p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    if p.ndim == 2:
+        p = p[None]
+    rast = np.asarray(rast, dtype=np.float64)
+    g = np.asarray(grad_rast, dtype=np.float64)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    B, height, width = rast.shape[:3]
+    out = np.zeros_like(p)
+    for b in range(B):
+        ids = rast[b, ..., 3].astype(np.int64) - 1
+        jj, ii = np.nonzero(ids >= 0)
+        t = tri[ids[jj, ii]]
+        fx = (ii + 0.5) / width * 2.0 - 1.0
+        fy = (jj + 0.5) / height * 2.0 - 1.0
+        v = p[b][t]
+        px = v[:, :, 0] - fx[:, None] * v[:, :, 3]
+        py = v[:, :, 1] - fy[:, None] * v[:, :, 3]
+        a0 = px[:, 1] * py[:, 2] - py[:, 1] * px[:, 2]
+        a1 = px[:, 2] * py[:, 0] - py[:, 2] * px[:, 0]
+        a2 = px[:, 0] * py[:, 1] - py[:, 0] * px[:, 1]
+        s = a0 + a1 + a2
+        s = np.where(s == 0.0, 1.0, s)
+        u, w_ = a0 / s, a1 / s
+        gu, gv = g[b, jj, ii, 0], g[b, jj, ii, 1]
+        dot = gu * u + gv * w_
+        da0, da1, da2 = (gu - dot) / s, (gv - dot) / s, -dot / s
+        dpx = np.stack([da1 * -py[:, 2] + da2 * py[:, 1], da0 * py[:, 2] + da2 * -py[:, 0], da0 * -py[:, 1] + da1 * py[:, 0]], axis=1)
+        dpy = np.stack([da1 * px[:, 2] + da2 * -px[:, 1], da0 * -px[:, 2] + da2 * px[:, 0], da0 * px[:, 1] + da1 * -px[:, 0]], axis=1)
+        for k in range(3):
+            np.add.at(out[b, :, 0], t[:, k], dpx[:, k])
+            np.add.at(out[b, :, 1], t[:, k], dpy[:, k])
+            np.add.at(out[b, :, 3], t[:, k], -fx * dpx[:, k] - fy * dpy[:, k])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# antialias  (mesh_rasterizer.py:107,128: dr.antialias(color, rast, pos_clip, tri, topology_hash=None, pos_gradient_boost=1.0))
+#
+# Published algorithm (Laine et al. 2020, section 3.5): every pair of horizontally / vertically adjacent pixels with different
+# triangle ids is a potential discontinuity.  Take the triangle of the surface CLOSER to the camera (z/w of `rast`; the
+# other pixel may be background), look at its edges: an edge is a SILHOUETTE edge if no other triangle shares it or if the
+# triangle that does lies on the same side of it in the image.  If a silhouette edge passes between the two pixel centres
+# -- horizontal pairs look at edges that are more vertical than horizontal, and vice versa -- the crossing point, at distance
+# t in [0, 1] from the centre of the closer triangle's pixel P towards the other pixel Q, estimates how far the closer
+# surface reaches: alpha = t - 1/2 > 0 blends alpha of P's colour into Q, alpha < 0 blends -alpha of Q's colour into P
+# (zero at the midpoint, one half at a pixel centre).  The position gradient is the gradient of alpha.
+#
+# Choices fixed here (PARITY UNPINNED, as above): pairs (p, p + x) and (p, p + y) of every pixel p; ties in z/w go to the
+# second pixel's triangle; window coordinates from the UNSNAPPED clip-space positions; a pair whose triangle has a vertex
+# at w <= 0 is skipped; the shared-edge partner of (triangle, edge) is the lowest-numbered other (triangle, edge) on the
+# same undirected vertex pair; an edge whose partner's far vertex has w <= 0 counts as a silhouette; every qualifying
+# edge of the triangle contributes (normally one).  All decisions are single float64 operations in a fixed order, which
+# the GPU kernel repeats -- the SET of blends is identical, their float32 sums are compared with a tolerance.
+# ---------------------------------------------------------------------------------------------------------------------
+def edge_partners(tri: np.ndarray) -> np.ndarray:
+    """``opp[3 t + e]`` = the vertex opposite edge ``e`` (the edge not touching local vertex ``e``) in the partner triangle
+    of triangle ``t`` across that edge, -1 on a boundary edge -- what nvdiffrast's topology hash answers."""
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    T = tri.shape[0]
+    table = {}
+    for t in range(T):
+        for e in range(3):
+            a, b = int(tri[t, (e + 1) % 3]), int(tri[t, (e + 2) % 3])
+            table.setdefault((min(a, b), max(a, b)), []).append(3 * t + e)
+    opp = np.full(3 * T, -1, dtype=np.int32)
+    for ids in table.values():
+        ids.sort()
+        for i in ids:
+            others = [j for j in ids if j != i]
+            if others:
+                j = others[0]
+                opp[i] = tri[j // 3, j % 3]
+    return opp
+
+
+def _window(p4, height, width):
+    """Window coordinates in pixels (y up) of one clip-space vertex, or None when it cannot be projected."""
+    x, y, _, w = (float(c) for c in p4)
+    if not (np.isfinite(x) and np.isfinite(y) and np.isfinite(w)) or not w > 0.0:
+        return None
+    return ((x / w) * 0.5 + 0.5) * float(width), ((y / w) * 0.5 + 0.5) * float(height)
+
+
+def _antialias_events(rast_b, pos_b, tri, opp, pixel_gradient=False):
+    """The blends of one view: tuples ``(dst (j, i), src (j, i), weight, sign, axis, (va, vb), (dA, dB))`` where ``dA / dB``
+    are the derivatives of ``t`` w.r.t. the window coordinates of the edge's two vertices."""
+    height, width = rast_b.shape[:2]
+    ids = rast_b[..., 3].astype(np.int64) - 1
+    zw = rast_b[..., 2]
+    events = []
+    for axis, (dj, di) in enumerate(((0, 1), (1, 0))):      # axis 0: horizontal pair, axis 1: vertical pair
+        t0 = ids[:height - dj, :width - di]
+        t1 = ids[dj:, di:]
+        jj, ii = np.nonzero(t0 != t1)
+        for j, i in zip(jj.tolist(), ii.tolist()):
+            a0, a1 = int(ids[j, i]), int(ids[j + dj, i + di])
+            if a0 >= 0 and a1 >= 0:
+                first = float(zw[j, i]) < float(zw[j + dj, i + di])
+            else:
+                first = a0 >= 0
+            t = a0 if first else a1
+            P = (j, i) if first else (j + dj, i + di)
+            Q = (j + dj, i + di) if first else (j, i)
+            vid = [int(k) for k in tri[t]]
+            win = [_window(pos_b[k], height, width) for k in vid]
+            if any(q is None for q in win):
+                continue
+            cx, cy = P[1] + 0.5, P[0] + 0.5
+            step = float((Q[1] - P[1]) if axis == 0 else (Q[0] - P[0]))       # +-1 along the pair's axis
+            for e in range(3):
+                ka, kb = (e + 1) % 3, (e + 2) % 3
+                (Ax, Ay), (Bx, By), (Ox, Oy) = win[ka], win[kb], win[e]
+                ex, ey = Bx - Ax, By - Ay
+                o2 = int(opp[3 * t + e])
+                if o2 >= 0:
+                    w2 = _window(pos_b[o2], height, width)
+                    if w2 is not None:
+                        s1 = ex * (Oy - Ay) - ey * (Ox - Ax)
+                        s2 = ex * (w2[1] - Ay) - ey * (w2[0] - Ax)
+                        if (s1 > 0.0) != (s2 > 0.0):
+                            continue                      # the partner continues the surface on the other side: not a silhouette
+                if axis == 0:
+                    if not abs(ey) >= abs(ex):
+                        continue
+                    sA, sB, base, span, centre = Ay - cy, By - cy, Ax, ex, cx
+                else:
+                    if not abs(ex) >= abs(ey):
+                        continue
+                    sA, sB, base, span, centre = Ax - cx, Bx - cx, Ay, ey, cy
+                if (sA > 0.0) == (sB > 0.0):
+                    continue
+                den = sA - sB
+                lam = sA / den
+                tt = ((base + span * lam) - centre) * step
+                if not (tt >= 0.0 and tt <= 1.0):
+                    continue
+                alpha = tt - 0.5
+                if alpha == 0.0:
+                    continue
+                # d tt / d (window coordinates of A and B): along the pair's axis (1 - lam, lam), across it span * d lam
+                dl_a, dl_b = -sB / (den * den), sA / (den * den)
+                along = (step * (1.0 - lam), step * lam)
+                across = (step * span * dl_a, step * span * dl_b)
+                dA = (along[0], across[0]) if axis == 0 else (across[0], along[0])      # (d/dx, d/dy) of vertex A
+                dB = (along[1], across[1]) if axis == 0 else (across[1], along[1])
+                if alpha > 0.0:
+                    events.append((Q, P, alpha, 1.0, axis, (vid[ka], vid[kb]), (dA, dB)))
+                else:
+                    events.append((P, Q, -alpha, -1.0, axis, (vid[ka], vid[kb]), (dA, dB)))
+    return events
+
+
+def antialias(color: np.ndarray, rast: np.ndarray, pos_clip: np.ndarray, tri: np.ndarray, opp: np.ndarray | None = None) -> np.ndarray:
+    """``dr.antialias(color, rast, pos, tri)`` (mesh_rasterizer.py:107,128): ``[B, H, W, C]`` float64."""
+    color = np.asarray(color, dtype=np.float32).astype(np.float64)
+    rast = np.asarray(rast, dtype=np.float32).astype(np.float64)
+    p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    if p.ndim == 2:
+        p = p[None]
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    opp = edge_partners(tri) if opp is None else opp
+    out = color.copy()
+    for b in range(rast.shape[0]):
+        for dst, src, wgt, _, _, _, _ in _antialias_events(rast[b], p[b], tri, opp):
+            out[b][dst] += wgt * (color[b][src] - color[b][dst])
+    return out
+
+
+def antialias_backward(color, rast, pos_clip, tri, grad_out, opp=None, pos_gradient_boost: float = 1.0):
+    """Gradients of ``antialias`` w.r.t. ``color`` and ``pos_clip`` (float64)."""
+    color = np.asarray(color, dtype=np.float32).astype(np.float64)
+    rast = np.asarray(rast, dtype=np.float32).astype(np.float64)
+    p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    if p.ndim == 2:
+        p = p[None]
+    g = np.asarray(grad_out, dtype=np.float64)
+    tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
+    opp = edge_partners(tri) if opp is None else opp
+    height, width = rast.shape[1:3]
+    grad_color = g.copy()
+    grad_pos = np.zeros_like(p)
+    for b in range(rast.shape[0]):
+        for dst, src, wgt, sign, _, (va, vb), (dA, dB) in _antialias_events(rast[b], p[b], tri, opp):
+            gd = g[b][dst]
+            grad_color[b][src] += wgt * gd
+            grad_color[b][dst] -= wgt * gd
+            dt = sign * float(np.dot(gd, color[b][src] - color[b][dst])) * pos_gradient_boost
+            for vtx, (ddx, ddy) in ((va, dA), (vb, dB)):
+                x, y, _, w = p[b, vtx]
+                gx, gy = dt * ddx, dt * ddy                               # d L / d window (x, y) of the vertex
+                grad_pos[b, vtx, 0] += gx * (0.5 * width / w)
+                grad_pos[b, vtx, 1] += gy * (0.5 * height / w)
+                grad_pos[b, vtx, 3] += gx * (-0.5 * width * x / (w * w)) + gy * (-0.5 * height * y / (w * w))
+    return grad_color, grad_pos
+
+
 def orbit_mvps(n_views: int, distance: float = 3.0, fov_deg: float = 40.0, near: float = 0.5, far: float = 8.0,
                elevation_deg: float = 20.0) -> np.ndarray:
     """``n_views`` model-view-projection matrices (float32 ``[n, 4, 4]``, OpenGL clip space) on a circle around the

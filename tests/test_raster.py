@@ -1,4 +1,5 @@
-"""Renderer slice: ``tssplat_amd.dr.rasterize`` / ``interpolate`` against oracle/raster_oracle.py.
+"""Renderer slice: ``tssplat_amd.dr.rasterize`` / ``interpolate`` / ``antialias`` against
+oracle/raster_oracle.py.
 
 CPU tests: the oracle's own invariants (watertight shared edges, orthographic interpolation reproduces the pixel grid,
 nearest depth, lower id on ties, dropped triangles) and the C ABI's argument checks.  GPU tests (``-m gpu``): triangle
@@ -118,6 +119,127 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.tsamd_rasterize(None, 0, 0, None, 0, 0, 0, None, None, None) == 0
 
 
+def _octasphere(levels=2, radius=0.7):
+    """A closed triangle mesh (subdivided octahedron), counter-clockwise seen from outside."""
+    v = [np.array(p, dtype=np.float64) for p in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))]
+    f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    for _ in range(levels):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            k = (min(a, b), max(a, b))
+            if k not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[k] = len(v) - 1
+            return cache[k]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        f = nf
+    return (radius * np.array(v)).astype(np.float32), np.array(f, dtype=np.int32)
+
+
+def test_edge_partners_of_closed_and_open_meshes():
+    _, tri = _octasphere(1)
+    opp = R.edge_partners(tri)
+    assert (opp >= 0).all()                                       # closed: every edge has a partner
+    for t in range(tri.shape[0]):
+        for e in range(3):
+            a, b = tri[t, (e + 1) % 3], tri[t, (e + 2) % 3]
+            o = opp[3 * t + e]
+            # the partner triangle holds the edge and the far vertex, and is not t itself
+            holders = [u for u in range(tri.shape[0]) if u != t and {a, b, o} == set(tri[u])]
+            assert len(holders) == 1
+    _, quad = _quad()
+    oq = R.edge_partners(quad)
+    assert list(oq) == [-1, 3, -1, -1, -1, 1]                     # only the diagonal (0, 2) is shared
+    # three triangles on one edge: partner = the lowest-numbered other (triangle, edge)
+    fan = np.array([[0, 1, 2], [1, 0, 3], [0, 1, 4]], dtype=np.int32)
+    of = R.edge_partners(fan)
+    assert of[3 * 0 + 2] == 3 and of[3 * 1 + 2] == 2 and of[3 * 2 + 2] == 2
+
+
+def test_antialias_of_an_axis_aligned_edge_is_exact_coverage():
+    # ONE triangle covering x < x_edge on the whole screen: along every row the boundary pixel pair is blended so that the alpha
+    # sum equals the covered area exactly (the closer surface reaches t pixels beyond its last covered centre).  (With a quad
+    # the rows whose boundary pixel belongs to the triangle that does not own the silhouette edge are left alone -- the
+    # published algorithm only looks at the edges of the pixel's own triangle.)
+    H, W = 6, 16
+    for x_edge in (-0.81, -0.33, 0.02, 0.4, 0.77):
+        pos = np.array([[-5, 0, 0, 1], [x_edge, -3, 0, 1], [x_edge, 3, 0, 1]], dtype=np.float32)
+        tri = np.array([[0, 1, 2]], dtype=np.int32)
+        rast = R.rasterize(pos, tri, (H, W))
+        alpha = np.clip(rast[..., 3:4], 0, 1)
+        aa = R.antialias(alpha, rast, pos[None], tri)
+        exact = (float(np.float32(x_edge)) * 0.5 + 0.5) * W * H               # (positions are float32)
+        assert abs(aa.sum() - exact) < 1e-9 * W * H
+        assert abs(alpha.sum() - exact) > 1e-3 or abs((x_edge * 0.5 + 0.5) * W % 1 - 0.5) < 1e-3     # and it did something
+
+
+def test_antialias_oracle_gradients_match_finite_differences():
+    v, tri = _octasphere(2)
+    pos = R.transform_pos(R.orbit_mvps(2), v)
+    H = W = 32
+    rast = R.rasterize(pos, tri, (H, W))
+    rng = np.random.default_rng(0)
+    col = rng.random((2, H, W, 3)).astype(np.float32)
+    g = rng.standard_normal(col.shape)
+    gc, gp = R.antialias_backward(col, rast, pos, tri, g, pos_gradient_boost=1.5)
+    assert np.abs(gp).sum() > 0 and (gp[..., 2] == 0).all()
+
+    def loss(c, p):
+        return float((R.antialias(c, rast, p, tri) * g).sum())
+    touched = np.unique(np.nonzero(np.abs(gp).sum(-1))[1])
+    for b, k, c in [(b, int(k), c) for b in range(2) for k in touched[:5] for c in (0, 1, 3)]:
+        pp, pm = pos.copy(), pos.copy()
+        pp[b, k, c] += 1e-3
+        pm[b, k, c] -= 1e-3
+        num = (loss(col, pp) - loss(col, pm)) / float(pp[b, k, c] - pm[b, k, c]) * 1.5
+        assert abs(gp[b, k, c] - num) <= 2e-3 * max(1.0, abs(num)), (b, k, c, gp[b, k, c], num)
+    # colour: the operator is linear in it
+    d = rng.standard_normal(col.shape).astype(np.float32) * 0.25
+    lin = loss(col + d, pos) - loss(col, pos)
+    assert abs(lin - float((gc * d.astype(np.float64)).sum())) <= 1e-5 * max(1.0, abs(lin))
+
+
+def test_rasterize_backward_oracle_matches_finite_differences():
+    v, tri = _octasphere(1)
+    pos = R.transform_pos(R.orbit_mvps(1), v)
+    H = W = 24
+    rast = R.rasterize(pos, tri, (H, W))
+    rng = np.random.default_rng(2)
+    g = rng.standard_normal(rast.shape)
+    g[..., 2:] = 0
+    gp = R.rasterize_backward(pos, tri, rast, g)
+    key = R.rasterize_ids(pos[0], tri, H, W)
+
+    def loss(p):
+        # same winners, barycentrics from the moved positions (the ids are piecewise constant)
+        return float((R.resolve(p[0], tri, key)[..., :2] * g[0, ..., :2]).sum())
+    for k, c in [(int(k), c) for k in np.unique(tri[(rast[0, ..., 3][rast[0, ..., 3] > 0] - 1).astype(int)])[:6] for c in (0, 1, 3)]:
+        pp, pm = pos.copy(), pos.copy()
+        pp[0, k, c] += 1e-3
+        pm[0, k, c] -= 1e-3
+        num = (loss(pp) - loss(pm)) / float(pp[0, k, c] - pm[0, k, c])
+        assert abs(gp[0, k, c] - num) <= 1e-3 * max(1.0, abs(num)), (k, c, gp[0, k, c], num)
+    assert (gp[..., 2] == 0).all()
+
+
+def test_c_abi_checks_antialias_arguments():
+    lib = _capi.load()
+    assert lib.tsamd_antialias_topology_workspace_bytes(-1) == -1
+    assert lib.tsamd_antialias_topology_workspace_bytes(10) == 64 * 16 + 30 * 4
+    assert lib.tsamd_antialias_topology(None, 5, None, None, None) == 1
+    assert lib.tsamd_antialias_topology(None, 0, None, None, None) == 0
+    assert lib.tsamd_antialias(None, None, None, None, None, 1, 3, 1, 4, 4, 0, None, None) == 1              # no channels
+    assert lib.tsamd_antialias(None, None, None, None, None, 1, 3, 1, 4, 4, 1, None, None) == 1              # null images
+    assert lib.tsamd_antialias(None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, None) == 0              # empty image
+    assert lib.tsamd_antialias_backward(None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, 1.0, None, None, None) == 1   # no output asked for
+    assert lib.tsamd_rasterize_backward(None, 1, 3, None, 1, 4, 4, None, None, None, None) == 1
+    assert b"null" in lib.tsamd_last_error()
+
+
 # ------------------------------------------------------------------ GPU parity ------------------------------------------------------------------
 
 def _surface_scene(kind, spheres, n_views, seed=0):
@@ -176,8 +298,8 @@ def test_rasterize_edge_cases_on_gpu():
         assert hit.any() and np.abs(got[..., :3][hit] - ref[..., :3][hit]).max() <= 5e-4
     with pytest.raises(NotImplementedError):
         dr.rasterize(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), resolution=[8, 8])        # grad_db defaults to True
-    with pytest.raises(NotImplementedError):
-        dr.antialias(None, None, None, None)
+    with pytest.raises(RuntimeError):
+        dr.antialias(None, None, None, None)                                                                    # not GPU tensors
     with pytest.raises(RuntimeError):
         dr.rasterize(ctx, torch.from_numpy(pos), torch.from_numpy(tri), resolution=[8, 8], grad_db=False)       # CPU tensors: no fallback
 
@@ -207,3 +329,76 @@ def test_interpolate_forward_backward(attr_batch_is_one):
     assert np.abs(attr.grad.cpu().numpy() - ga).max() <= 2e-5 * np.abs(ga).max()            # fp32 atomics, arbitrary order
     assert np.abs(rast_in.grad.cpu().numpy() - gr).max() <= 2e-5 * max(np.abs(gr).max(), 1e-30)
     assert (rast_in.grad[..., 2:] == 0).all()
+
+
+@pytest.mark.gpu
+def test_topology_table_matches_the_oracle():
+    import torch
+    import tssplat_amd.dr as dr
+    _, tri, _ = _surface_scene("kuhn8", 4, 1)
+    rng = np.random.default_rng(4)
+    extra = rng.integers(0, 50, (300, 3)).astype(np.int32)                    # a soup: boundary edges, edges with 3+ triangles, repeated vertices
+    for t in (tri, extra, np.concatenate([tri[:500], tri[:40]])):
+        topo = dr.antialias_construct_topology_hash(torch.from_numpy(np.ascontiguousarray(t)).cuda())
+        assert np.array_equal(topo.opp.cpu().numpy(), R.edge_partners(t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,spheres,views,res,channels", [("kuhn4", 3, 2, (64, 64), 1), ("kuhn8", 5, 3, (128, 96), 3)])
+def test_antialias_forward_backward(kind, spheres, views, res, channels):
+    import torch
+    import tssplat_amd.dr as dr
+    pos_clip, tri, _ = _surface_scene(kind, spheres, views)
+    ctx = dr.RasterizeCudaContext()
+    tri_d = torch.from_numpy(tri).cuda()
+    pos = torch.from_numpy(pos_clip).cuda().requires_grad_(True)
+    rast, _ = dr.rasterize(ctx, pos, tri_d, resolution=list(res), grad_db=False)
+    rast_np = rast.detach().cpu().numpy()
+    rng = np.random.default_rng(7)
+    if channels == 1:
+        col_np = np.clip(rast_np[..., 3:4], 0, 1).astype(np.float32)          # the reference's alpha image (mesh_rasterizer.py:106)
+    else:
+        col_np = rng.random(rast_np.shape[:3] + (channels,)).astype(np.float32)
+    col = torch.from_numpy(col_np).cuda().requires_grad_(True)
+    out = dr.antialias(col, rast, pos, tri_d, topology_hash=None, pos_gradient_boost=2.0)
+    ref = R.antialias(col_np, rast_np, pos_clip, tri)
+    n_changed = int((np.abs(ref - col_np).sum(-1) > 0).sum())
+    assert n_changed > 20                                                      # silhouettes were found
+    assert np.abs(out.detach().cpu().numpy() - ref).max() <= 2e-6             # same set of blends (a different decision shows as ~0.1)
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(torch.from_numpy(g).cuda())
+    gc, gp = R.antialias_backward(col_np, rast_np, pos_clip, tri, g, pos_gradient_boost=2.0)
+    assert np.abs(col.grad.cpu().numpy() - gc).max() <= 1e-5 * max(1.0, np.abs(gc).max())
+    # rast's (u, v) carry no gradient here (out does not depend on them), so pos.grad is the antialias term alone
+    assert np.abs(gp).max() > 0
+    assert np.abs(pos.grad.cpu().numpy() - gp).max() <= 2e-5 * np.abs(gp).max()
+    # an explicit topology hash gives the same image (up to the order of the fp32 atomics on pixels with two blends)
+    out2 = dr.antialias(col.detach(), rast, pos.detach(), tri_d, topology_hash=dr.antialias_construct_topology_hash(tri_d))
+    assert (out2 - out.detach()).abs().max().item() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_rasterize_backward_through_interpolate():
+    import torch
+    import tssplat_amd.dr as dr
+    views, res = 2, (96, 96)
+    pos_clip, tri, v = _surface_scene("kuhn8", 4, views)
+    ctx = dr.RasterizeCudaContext()
+    tri_d = torch.from_numpy(tri).cuda()
+    pos = torch.from_numpy(pos_clip).cuda().requires_grad_(True)
+    attr_np = v[None].astype(np.float32)
+    attr = torch.from_numpy(attr_np).cuda()
+    rast, _ = dr.rasterize(ctx, pos, tri_d, resolution=list(res), grad_db=False)
+    out, _ = dr.interpolate(attr, rast, tri_d)
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(torch.from_numpy(g).cuda())
+    rast_np = rast.detach().cpu().numpy()
+    _, gr = R.interpolate_backward(attr_np, rast_np, tri, g)
+    gp = R.rasterize_backward(pos_clip, tri, rast_np, gr)
+    got = pos.grad.cpu().numpy()
+    assert np.abs(gp).max() > 0 and (got[..., 2] == 0).all()
+    # fp32 quotient rule on sub-pixel triangles: the edge functions are differences of nearly equal products
+    scale = np.abs(gp).max()
+    assert np.abs(got - gp).max() <= 2e-3 * scale
+    assert np.abs(got - gp).mean() <= 2e-5 * scale

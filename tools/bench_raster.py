@@ -4,7 +4,7 @@ of the headline scene (512 x kuhn19: 2.2 M boundary triangles, 1.1 M surface ver
 
     python tools/bench_raster.py [--spheres 512 --views 8 --res 512 --reps 20]
 
-One JSON line: pixels/s of rasterize (+ interpolate), and a roofline object for the rasterize pair of kernels with
+One JSON line: pixels/s of rasterize (+ interpolate, antialias, the backward passes), and a roofline object for the rasterize pair of kernels with
 ALGORITHMIC bytes per call = views x (12 B x triangles + 16 B x vertices + 16 B x pixels) -- every index and clip-space
 vertex read once per view, every output pixel written once -- against the 8 TB/s HBM peak.  The first slice is one
 lane per (view, triangle) with 64-bit atomics: expect a small fraction.
@@ -66,11 +66,37 @@ def main():
         out.backward(g)
 
     t_fb = timed(fwd_bwd, args.reps)
+
+    # the reference's alpha path (mesh_rasterizer.py:103-108): rasterize -> clamp(id) -> antialias, and its backward to pos
+    pos_g = pos.clone().requires_grad_(True)
+    alpha = torch.clamp(rast[..., -1:], 0, 1).contiguous()
+    topo = dr.antialias_construct_topology_hash(tri)
+    t_topo = timed(lambda: dr.antialias_construct_topology_hash(tri), max(2, args.reps // 4))
+    t_aa = timed(lambda: dr.antialias(alpha, rast, pos, tri, topology_hash=topo), args.reps)
+    ga = torch.randn_like(alpha)
+
+    def aa_fwd_bwd():
+        pos_g.grad = None
+        dr.antialias(alpha, rast, pos_g, tri, topology_hash=topo).backward(ga)
+
+    t_aa_fb = timed(aa_fwd_bwd, args.reps)
+    aa = dr.antialias(alpha, rast, pos, tri, topology_hash=topo)
+    blended = int(((aa - alpha).abs().sum(-1) > 0).sum())
+
+    def rast_interp_fwd_bwd():
+        pos_g.grad = None
+        r, _ = dr.rasterize(ctx, pos_g, tri, resolution=res, grad_db=False)
+        out, _ = dr.interpolate(attr.detach(), r, tri)
+        out.backward(g)
+
+    t_rb = timed(rast_interp_fwd_bwd, args.reps)
     T, V, px = int(tri.shape[0]), int(pos.shape[1]), args.views * args.res * args.res
     b_alg = args.views * (12.0 * T + 16.0 * V) + 16.0 * px
     print(json.dumps({
         "metric": "pixels/s (rasterize, 8 views x 512^2 of the 512-sphere surface)", "value": px / (t_rast * 1e-3), "unit": "pixels/s",
         "rasterize_ms": t_rast, "interpolate_ms": t_interp, "interpolate_fwd_bwd_ms": t_fb,
+        "antialias_ms": t_aa, "antialias_fwd_bwd_ms": t_aa_fb, "antialias_topology_ms": t_topo, "antialias_blended_pixels": blended,
+        "rasterize_interpolate_fwd_bwd_to_pos_ms": t_rb,
         "triangle_views_per_s": args.views * T / (t_rast * 1e-3),
         "config": {"workload": f"{args.spheres} x {args.scene} surface: {T} triangles, {V} vertices; {args.views} views x {args.res}^2, "
                                f"coverage {cover:.3f}", "dtype": "f32 (coverage / depth test: int64 + f64)"},

@@ -20,7 +20,7 @@ _OBJ = os.path.join(_HERE, "_obj")
 ARCH = "gfx950"
 
 SOURCES = ["plan.cpp", "conflict_opt.cpp", "stream_plan.cpp", "stream_capi.cpp", "capi.cpp", "kernels.hip", "stream_kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
-           "raster_capi.cpp", "raster_kernels.hip"]
+           "raster_capi.cpp", "raster_kernels.hip", "aa_kernels.hip"]
 HEADERS = ["plan.h", "conflict_opt.h", "stream_plan.h", "stream_kernels.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]

@@ -71,4 +71,76 @@ int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_
     return TSAMD_OK;
 }
 
+int tsamd_rasterize_backward(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
+                             int32_t height, int32_t width, const float *rast_dev, const float *grad_rast_dev, float *grad_pos_dev, void *stream)
+{
+    int rc = check_image(batch, height, width);
+    if (rc) return rc;
+    if (n_vertices < 0 || n_triangles < 0) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size");
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (batch * n_vertices > 0 && !grad_pos_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_pos_dev is null");
+    if (pixels > 0 && n_triangles > 0 && (!pos_clip_dev || !tri_dev || !rast_dev || !grad_rast_dev))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
+    TSAMD_HIP(tsamd::launch_rasterize_backward(pos_clip_dev, batch, n_vertices, tri_dev, n_triangles, height, width, rast_dev, grad_rast_dev,
+                                               grad_pos_dev, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int64_t tsamd_antialias_topology_workspace_bytes(int64_t n_triangles)
+{
+    if (n_triangles < 0 || n_triangles >= (int64_t(1) << 30)) return -1;   // (triangle, edge) ids are 32-bit
+    return tsamd::antialias_topology_workspace_bytes(n_triangles);
+}
+
+int tsamd_antialias_topology(const int32_t *tri_dev, int64_t n_triangles, void *workspace_dev, int32_t *edge_partner_dev, void *stream)
+{
+    if (n_triangles < 0 || n_triangles >= (int64_t(1) << 30)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "n_triangles out of range (0 .. 2^30 - 1)");
+    if (n_triangles > 0 && (!tri_dev || !workspace_dev || !edge_partner_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
+    TSAMD_HIP(tsamd::launch_antialias_topology(tri_dev, n_triangles, workspace_dev, edge_partner_dev, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+namespace {
+int check_antialias(int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels)
+{
+    int rc = check_image(batch, height, width);
+    if (rc) return rc;
+    if (n_vertices < 0 || n_triangles < 0 || n_channels < 1) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or n_channels < 1");
+    return TSAMD_OK;
+}
+}  // namespace
+
+int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
+                    int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
+                    void *stream)
+{
+    int rc = check_antialias(batch, n_vertices, n_triangles, height, width, n_channels);
+    if (rc) return rc;
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (pixels > 0 && (!color_dev || !rast_dev || !out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "color_dev / rast_dev / out_dev is null");
+    if (pixels > 0 && n_triangles > 0 && (!pos_clip_dev || !tri_dev || !edge_partner_dev))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev / edge_partner_dev is null");
+    TSAMD_HIP(tsamd::launch_antialias(color_dev, rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height, width,
+                                      n_channels, out_dev, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev,
+                             const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+                             int32_t n_channels, const float *grad_out_dev, float pos_gradient_boost, float *grad_color_dev, float *grad_pos_dev,
+                             void *stream)
+{
+    int rc = check_antialias(batch, n_vertices, n_triangles, height, width, n_channels);
+    if (rc) return rc;
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (!grad_color_dev && !grad_pos_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_color_dev and grad_pos_dev are both null");
+    if (pixels > 0 && (!color_dev || !rast_dev || !grad_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "color_dev / rast_dev / grad_out_dev is null");
+    if (pixels > 0 && n_triangles > 0 && (!pos_clip_dev || !tri_dev || !edge_partner_dev))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev / edge_partner_dev is null");
+    TSAMD_HIP(tsamd::launch_antialias_backward(color_dev, rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height,
+                                               width, n_channels, grad_out_dev, pos_gradient_boost, grad_color_dev, grad_pos_dev,
+                                               static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
 }  // extern "C"

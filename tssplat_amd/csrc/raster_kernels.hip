@@ -168,6 +168,51 @@ __global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *po
     rast[gid] = make_float4(fminf(fmaxf(b0, 0.f), 1.f), fminf(fmaxf(b1, 0.f), 1.f), fminf(fmaxf(z / w, -1.f), 1.f), float(t + 1));
 }
 
+// d (u, v) / d clip-space positions of the winning triangle (oracle/raster_oracle.py::rasterize_backward): the barycentrics
+// are ratios of the homogeneous edge functions of `resolve`, so this is their quotient rule; z/w and the id carry no gradient
+// (as in nvdiffrast), the clamps of the forward are treated as inactive.  fp32 atomics into grad_pos.
+__global__ __launch_bounds__(256) void rasterize_backward_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t n_tri, int64_t batch,
+                                                                 int height, int width, const float4 *rast, const float4 *grad_rast, float4 *grad_pos)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t hw = int64_t(height) * width;
+    if (gid >= batch * hw) return;
+    const int64_t t = int64_t(rast[gid].w) - 1;
+    if (t < 0 || t >= n_tri) return;
+    const float4 g = grad_rast[gid];
+    if (g.x == 0.f && g.y == 0.f) return;
+    const int64_t b = gid / hw, pix = gid - b * hw;
+    const int py = int(pix / width), px = int(pix - int64_t(py) * width);
+    const int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) return;
+    const float4 *pv = pos + b * n_vertices;
+    const float4 v0 = pv[i0], v1 = pv[i1], v2 = pv[i2];
+    const float fx = (float(px) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py) + 0.5f) / float(height) * 2.f - 1.f;
+    const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
+    const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
+    const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
+    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+    float s = a0 + a1 + a2;
+    s = s == 0.f ? 1.f : s;
+    const float is = 1.f / s;
+    const float u = a0 * is, v = a1 * is;
+    const float dot = g.x * u + g.y * v;
+    const float da0 = (g.x - dot) * is, da1 = (g.y - dot) * is, da2 = -dot * is;
+    const float d0x = da1 * -p2y + da2 * p1y, d0y = da1 * p2x + da2 * -p1x;
+    const float d1x = da0 * p2y + da2 * -p0y, d1y = da0 * -p2x + da2 * p0x;
+    const float d2x = da0 * -p1y + da1 * p0y, d2y = da0 * p1x + da1 * -p0x;
+    float *gp = reinterpret_cast<float *>(grad_pos + b * n_vertices);
+    atomicAdd(gp + 4 * int64_t(i0) + 0, d0x);
+    atomicAdd(gp + 4 * int64_t(i0) + 1, d0y);
+    atomicAdd(gp + 4 * int64_t(i0) + 3, -fx * d0x - fy * d0y);
+    atomicAdd(gp + 4 * int64_t(i1) + 0, d1x);
+    atomicAdd(gp + 4 * int64_t(i1) + 1, d1y);
+    atomicAdd(gp + 4 * int64_t(i1) + 3, -fx * d1x - fy * d1y);
+    atomicAdd(gp + 4 * int64_t(i2) + 0, d2x);
+    atomicAdd(gp + 4 * int64_t(i2) + 1, d2y);
+    atomicAdd(gp + 4 * int64_t(i2) + 3, -fx * d2x - fy * d2y);
+}
+
 __global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
                                                           const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw, float *out)
 {
@@ -242,6 +287,21 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
     }
     hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
                        n_vertices, batch, height, width, keys, reinterpret_cast<float4 *>(rast));
+    return hipGetLastError();
+}
+
+hipError_t launch_rasterize_backward(const float *pos_clip, int64_t batch, int64_t n_vertices, const int32_t *tri, int64_t n_tri, int height, int width,
+                                     const float *rast, const float *grad_rast, float *grad_pos, hipStream_t stream)
+{
+    if (batch * n_vertices > 0) {
+        const hipError_t e = hipMemsetAsync(grad_pos, 0, size_t(batch) * size_t(n_vertices) * 4 * sizeof(float), stream);
+        if (e != hipSuccess) return e;
+    }
+    const int64_t pixels = batch * int64_t(height) * width;
+    if (pixels <= 0 || n_tri <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rasterize_backward_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri, n_vertices,
+                       n_tri, batch, height, width, reinterpret_cast<const float4 *>(rast), reinterpret_cast<const float4 *>(grad_rast),
+                       reinterpret_cast<float4 *>(grad_pos));
     return hipGetLastError();
 }
 

@@ -1,23 +1,20 @@
-"""The two nvdiffrast operators the reference's renderer uses, on the MI355X kernels (first slice).
+"""The nvdiffrast operators the reference's renderer uses, on the MI355X kernels.
 
 /root/reference/renderers/mesh_rasterizer.py does ``import nvdiffrast.torch as dr`` (:2) and calls
 
     self.glctx = dr.RasterizeCudaContext()                                                          :34
     rast_out, _ = dr.rasterize(self.glctx, pos_clip, t_pos_idx, resolution=res, grad_db=False)      :103
     positions_all, _ = dr.interpolate(v_pos[None, ...], rast_out, t_pos_idx)                        :117  (:145, :153)
-    alpha = dr.antialias(...)                                                                        :107, :128   NOT in this slice
+    alpha = dr.antialias(alpha, rast_out, pos_clip, t_pos_idx, topology_hash=None, pos_gradient_boost=1.0)   :107, :128
 
-This module offers the first three under the same names and argument order (``import tssplat_amd.dr as dr``).  nvdiffrast
-is a separate library, not vendored by the reference and not installed here: the semantics are a restatement of its
-published algorithm, pinned down in oracle/raster_oracle.py -- PARITY UNPINNED against the library itself.
+This module offers all four under the same names and argument order (``import tssplat_amd.dr as dr``), differentiable
+where nvdiffrast is: ``rasterize`` w.r.t. ``pos`` through ``(u, v)``, ``interpolate`` w.r.t. ``attr`` and ``rast``,
+``antialias`` w.r.t. ``color`` and ``pos``.  nvdiffrast is a separate library, not vendored by the reference and not
+installed here: the semantics are a restatement of its published algorithm, pinned down in oracle/raster_oracle.py --
+PARITY UNPINNED against the library itself.
 
-What this slice does not do, loudly:
-* ``antialias`` raises ``NotImplementedError`` -- and with it goes the silhouette gradient the reference's alpha loss
-  lives on; this is a stand-alone operator pair with its own oracle and bench, not yet a renderer for trainer.py;
-* ``rasterize`` is not differentiable: nvdiffrast propagates d(u, v) / d(pos) through it, here ``rast`` is returned
-  detached (``interpolate`` still produces the gradient w.r.t. ``rast``'s (u, v), so nothing is lost silently downstream
-  of this module -- it simply stops at ``rast``).  ``grad_db=True`` and ``ranges`` are rejected;
-* no polygon clipping: a triangle with a vertex at ``w <= 0`` is dropped.
+What it does not do, loudly: ``grad_db=True``, ``ranges`` (range mode), ``rast_db`` / ``diff_attrs`` and OpenGL contexts are
+rejected; no polygon clipping (a triangle with a vertex at ``w <= 0`` is dropped); no depth peeling, no texture sampling.
 """
 from __future__ import annotations
 
@@ -26,7 +23,7 @@ import torch
 from . import _capi
 from .tet_spheres_ext import _device_ctx, _stream_ptr
 
-__all__ = ["RasterizeCudaContext", "rasterize", "interpolate", "antialias"]
+__all__ = ["RasterizeCudaContext", "rasterize", "interpolate", "antialias", "antialias_construct_topology_hash"]
 
 _lib = _capi.load()
 
@@ -63,25 +60,46 @@ def _check_tri(tri: torch.Tensor, device) -> torch.Tensor:
     return tri.contiguous()
 
 
+class _RasterizeFunc(torch.autograd.Function):
+    """``rast`` with the gradient of its ``(u, v)`` channels w.r.t. ``pos`` (tsamd_rasterize_backward)."""
+
+    @staticmethod
+    def forward(ctx, pos, tri, glctx, height, width):
+        B, V = int(pos.shape[0]), int(pos.shape[1])
+        rast = torch.empty((B, height, width, 4), dtype=torch.float32, device=pos.device)
+        ws = glctx.workspace(B, V, height, width, pos.device)
+        with _device_ctx(pos.device):
+            _capi.check(_lib.tsamd_rasterize(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), height, width, ws.data_ptr(),
+                                             rast.data_ptr(), _stream_ptr(pos.device)))
+        ctx.save_for_backward(pos, tri, rast)
+        return rast
+
+    @staticmethod
+    def backward(ctx, grad_rast):
+        pos, tri, rast = ctx.saved_tensors
+        B, V, H, W = int(pos.shape[0]), int(pos.shape[1]), int(rast.shape[1]), int(rast.shape[2])
+        g = grad_rast.contiguous()
+        grad_pos = torch.empty_like(pos)
+        with _device_ctx(pos.device):
+            _capi.check(_lib.tsamd_rasterize_backward(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), H, W, rast.data_ptr(),
+                                                      g.data_ptr(), grad_pos.data_ptr(), _stream_ptr(pos.device)))
+        return grad_pos, None, None, None, None
+
+
 def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor, resolution, ranges=None, grad_db: bool = True):
     """``(rast, rast_db)``: ``rast[B, H, W, 4] = (u, v, z/w, triangle_id + 1)``, zeros on background; ``rast_db`` is an empty
-    tensor (image-space derivatives are only produced with ``grad_db=True``, which this slice rejects)."""
+    tensor (image-space derivatives are only produced with ``grad_db=True``, which is rejected: the reference passes False)."""
     if ranges is not None:
-        raise NotImplementedError("tssplat_amd.dr.rasterize: range mode is not part of this slice")
+        raise NotImplementedError("tssplat_amd.dr.rasterize: range mode is not supported")
     if grad_db:
-        raise NotImplementedError("tssplat_amd.dr.rasterize: grad_db=True is not part of this slice (the reference passes grad_db=False)")
-    pos = _check_cuda_f32("pos", pos.detach())
+        raise NotImplementedError("tssplat_amd.dr.rasterize: grad_db=True is not supported (the reference passes grad_db=False)")
+    pos = _check_cuda_f32("pos", pos)
     if pos.dim() != 3 or pos.shape[2] != 4:
         raise RuntimeError("tssplat_amd.dr.rasterize: pos must be [B, V, 4] clip-space positions (instanced mode)")
     tri = _check_tri(tri, pos.device)
     height, width = int(resolution[0]), int(resolution[1])
-    B, V = int(pos.shape[0]), int(pos.shape[1])
-    rast = torch.empty((B, height, width, 4), dtype=torch.float32, device=pos.device)
-    ws = glctx.workspace(B, V, height, width, pos.device)
-    with _device_ctx(pos.device):
-        _capi.check(_lib.tsamd_rasterize(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), height, width, ws.data_ptr(),
-                                         rast.data_ptr(), _stream_ptr(pos.device)))
-    return rast, torch.empty((B, height, width, 0), dtype=torch.float32, device=pos.device)
+    rast = _RasterizeFunc.apply(pos, tri, glctx, height, width)
+    return rast, torch.empty((int(pos.shape[0]), height, width, 0), dtype=torch.float32, device=pos.device)
 
 
 class _InterpolateFunc(torch.autograd.Function):
@@ -129,6 +147,88 @@ def interpolate(attr: torch.Tensor, rast: torch.Tensor, tri: torch.Tensor, rast_
     return out, torch.empty(tuple(rast.shape[:3]) + (0,), dtype=torch.float32, device=rast.device)
 
 
-def antialias(*args, **kwargs):
-    raise NotImplementedError("tssplat_amd.dr.antialias is not part of this slice (SURVEY 8(f) row 4: rasterize + interpolate only); "
-                              "the reference calls it at renderers/mesh_rasterizer.py:107,128")
+class TopologyHash:
+    """``dr.antialias_construct_topology_hash(tri)``: the edge partner table of one triangle list (``opp[3 t + e]`` = the
+    vertex across edge ``e`` of triangle ``t``, -1 on a boundary)."""
+
+    def __init__(self, tri: torch.Tensor):
+        tri = _check_tri(tri, tri.device)
+        if not tri.is_cuda:
+            raise RuntimeError("tssplat_amd.dr: tri must be a GPU tensor (there is no CPU fallback)")
+        T = int(tri.shape[0])
+        self.n_triangles = T
+        self.key = (tri.data_ptr(), tri._version, T, tri.device)
+        self.opp = torch.empty(3 * T, dtype=torch.int32, device=tri.device)
+        need = int(_lib.tsamd_antialias_topology_workspace_bytes(T))
+        if need < 0:
+            raise RuntimeError("tssplat_amd.dr: too many triangles for the topology table")
+        ws = torch.empty(max(need, 8), dtype=torch.uint8, device=tri.device)
+        with _device_ctx(tri.device):
+            _capi.check(_lib.tsamd_antialias_topology(tri.data_ptr(), T, ws.data_ptr(), self.opp.data_ptr(), _stream_ptr(tri.device)))
+
+
+def antialias_construct_topology_hash(tri: torch.Tensor) -> TopologyHash:
+    return TopologyHash(tri)
+
+
+_last_topology: dict = {}
+
+
+def _topology_for(tri: torch.Tensor) -> TopologyHash:
+    """``topology_hash=None``: nvdiffrast rebuilds the table on every call; the last one per device is kept here as long as
+    the same (unmodified) index tensor comes back."""
+    key = (tri.data_ptr(), tri._version, int(tri.shape[0]), tri.device)
+    hit = _last_topology.get(tri.device)
+    if hit is None or hit.key != key:
+        hit = TopologyHash(tri)
+        _last_topology[tri.device] = hit
+    return hit
+
+
+class _AntialiasFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp, boost):
+        B, H, W, Cn = (int(k) for k in color.shape)
+        V, T = int(pos.shape[1]), int(tri.shape[0])
+        out = torch.empty_like(color)
+        with _device_ctx(color.device):
+            _capi.check(_lib.tsamd_antialias(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W, Cn,
+                                             out.data_ptr(), _stream_ptr(color.device)))
+        ctx.save_for_backward(color, rast, pos, tri, opp)
+        ctx.boost = float(boost)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        color, rast, pos, tri, opp = ctx.saved_tensors
+        B, H, W, Cn = (int(k) for k in color.shape)
+        V, T = int(pos.shape[1]), int(tri.shape[0])
+        g = grad_out.contiguous()
+        grad_color = torch.empty_like(color) if ctx.needs_input_grad[0] else None
+        grad_pos = torch.empty_like(pos) if ctx.needs_input_grad[2] else None
+        if grad_color is None and grad_pos is None:
+            return None, None, None, None, None, None
+        with _device_ctx(color.device):
+            _capi.check(_lib.tsamd_antialias_backward(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W,
+                                                      Cn, g.data_ptr(), ctx.boost, None if grad_color is None else grad_color.data_ptr(),
+                                                      None if grad_pos is None else grad_pos.data_ptr(), _stream_ptr(color.device)))
+        return grad_color, None, grad_pos, None, None, None
+
+
+def antialias(color: torch.Tensor, rast: torch.Tensor, pos: torch.Tensor, tri: torch.Tensor, topology_hash=None, pos_gradient_boost: float = 1.0):
+    """``dr.antialias`` (mesh_rasterizer.py:107,128): ``color[B, H, W, C]`` with the silhouette pixels blended by the position
+    of the silhouette edge between the pixel centres; differentiable w.r.t. ``color`` and ``pos`` (``rast`` carries none)."""
+    color = _check_cuda_f32("color", color)
+    rast = _check_cuda_f32("rast", rast.detach())
+    pos = _check_cuda_f32("pos", pos)
+    if color.dim() != 4 or rast.dim() != 4 or rast.shape[3] != 4 or tuple(color.shape[:3]) != tuple(rast.shape[:3]):
+        raise RuntimeError("tssplat_amd.dr.antialias: color must be [B, H, W, C] and rast [B, H, W, 4] of the same image size")
+    if pos.dim() != 3 or pos.shape[2] != 4 or pos.shape[0] != rast.shape[0]:
+        raise RuntimeError("tssplat_amd.dr.antialias: pos must be [B, V, 4] clip-space positions (instanced mode)")
+    if color.device != rast.device or pos.device != rast.device:
+        raise RuntimeError("tssplat_amd.dr.antialias: color, rast and pos must live on the same device")
+    tri = _check_tri(tri, rast.device)
+    topo = _topology_for(tri) if topology_hash is None else topology_hash
+    if not isinstance(topo, TopologyHash) or topo.n_triangles != int(tri.shape[0]) or topo.opp.device != rast.device:
+        raise RuntimeError("tssplat_amd.dr.antialias: topology_hash does not belong to this triangle list")
+    return _AntialiasFunc.apply(color, rast, pos, tri, topo.opp, float(pos_gradient_boost))
