@@ -23,10 +23,13 @@ against the library itself.  Where the published description leaves a choice, th
   every pixel exactly once (nvdiffrast's CUDA rasteriser snaps to 1/16 pixel; the rule is the same kind);
 * no polygon clipping: a triangle with a vertex at w <= 0, a non-finite coordinate or a snapped coordinate beyond
   +-2^22 sub-pixel units is dropped; fragments with z/w outside [-1, 1] are dropped per pixel;
-* depth test: z/w of the three vertices interpolated linearly in window space with the integer edge functions as weights,
-  in float64 with one fixed operation order, quantised to 32 bits; equal depth keys are resolved towards the LOWER
-  triangle index.  The GPU kernel performs the same float64 operations in the same order (IEEE basic operations are
-  correctly rounded on both sides), which is what makes the triangle ids BIT-EXACT between the two.
+* depth test: z/w of the three vertices (rounded to float32) interpolated linearly in window space as a PLANE EQUATION
+  ``z/w = z0 + zx (x - x0) + zy (y - y0)`` over the snapped coordinates -- a rasteriser's usual depth set-up: two divisions
+  per triangle, two multiplies and two adds per fragment -- in FLOAT32 with one fixed operation order, every operation
+  rounded on its own (no fused multiply-add), scaled to a 32-bit key; equal keys are resolved towards the LOWER triangle
+  index.  The GPU kernel performs the same float32 operations in the same order (IEEE basic operations are correctly
+  rounded on both sides), which is what makes the triangle ids BIT-EXACT between the two.  (Rounds 3a used float64
+  edge-function weights; float32 is what a hardware or CUDA rasteriser computes depth in and costs a quarter.)
 * ``(u, v, z/w)`` are then recomputed from the unsnapped clip-space positions (homogeneous 2-D edge functions, as
   nvdiffrast's fragment stage does), clamped to [0, 1] / [-1, 1]: float64 here, float32 on the GPU -- compared with a
   tolerance.
@@ -43,7 +46,7 @@ NO_FRAGMENT = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
 def snap_vertices(pos_clip: np.ndarray, height: int, width: int):
-    """Window coordinates in 1/256 pixel (int64), NDC depth (float64) and a validity mask per vertex of one view.
+    """Window coordinates in 1/256 pixel (int64), NDC depth (float32) and a validity mask per vertex of one view.
 
     Every operation is a single correctly rounded float64 operation, in this order -- the GPU kernel repeats them."""
     p = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
@@ -57,7 +60,7 @@ def snap_vertices(pos_clip: np.ndarray, height: int, width: int):
     ok &= (np.abs(X) <= COORD_LIMIT) & (np.abs(Y) <= COORD_LIMIT)
     X = np.where(ok, X, 0.0).astype(np.int64)
     Y = np.where(ok, Y, 0.0).astype(np.int64)
-    zw = np.where(ok, z / ws, 0.0)
+    zw = np.where(ok, z / ws, 0.0).astype(np.float32)
     return X, Y, zw, ok
 
 
@@ -75,7 +78,7 @@ def rasterize_ids(pos_clip: np.ndarray, tri: np.ndarray, height: int, width: int
         if not (ok[i0] and ok[i1] and ok[i2]):
             continue
         x0, y0, x1, y1, x2, y2 = int(X[i0]), int(Y[i0]), int(X[i1]), int(Y[i1]), int(X[i2]), int(Y[i2])
-        z0, z1, z2 = float(ZW[i0]), float(ZW[i1]), float(ZW[i2])
+        z0, z1, z2 = ZW[i0], ZW[i1], ZW[i2]                     # numpy float32 scalars: every operation below rounds to float32
         area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
         if area == 0:
             continue
@@ -99,11 +102,17 @@ def rasterize_ids(pos_clip: np.ndarray, tri: np.ndarray, height: int, width: int
             inside &= (e > 0) | ((e == 0) & _top_left(dx, dy))
         if not inside.any():
             continue
-        a = (e0 + e1) + e2                                # = |2 area| at every pixel
-        zw = ((e0.astype(np.float64) * z0 + e1.astype(np.float64) * z1) + e2.astype(np.float64) * z2) / a.astype(np.float64)
-        inside &= (zw >= -1.0) & (zw <= 1.0)
-        q = np.floor((zw + 1.0) * DEPTH_SCALE)
-        q = np.clip(q, 0.0, 4294967295.0).astype(np.uint64)
+        # depth plane through the three snapped vertices (area > 0 after the orientation): float32, one rounding per operation
+        f32 = np.float32
+        A = f32(np.float64(abs(area)))
+        d1, d2 = z1 - z0, z2 - z0
+        zx = (d1 * f32(y2 - y0) - d2 * f32(y1 - y0)) / A
+        zy = (d2 * f32(x1 - x0) - d1 * f32(x2 - x0)) / A
+        zw = (z0 + zx * (cx - x0).astype(f32)) + zy * (cy - y0).astype(f32)
+        assert zw.dtype == np.float32
+        inside &= (zw >= f32(-1.0)) & (zw <= f32(1.0))
+        q = (zw + f32(1.0)) * f32(DEPTH_SCALE)                  # float32, in [0, 2^32]: the scaling is exact
+        q = np.where(q >= f32(4294967296.0), np.uint64(0xFFFFFFFF), np.where(inside, q, f32(0)).astype(np.uint64))
         k = (q << np.uint64(32)) | np.uint64(t)
         sub = key[py0:py1 + 1, px0:px1 + 1]
         np.minimum(sub, np.where(inside, k, NO_FRAGMENT), out=sub)

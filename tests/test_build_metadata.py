@@ -28,3 +28,13 @@ def test_tile_kernels_have_no_static_lds_and_do_not_spill():
     assert len(default) == 1 and default[0]["vgpr_count"] <= 80, default      # 6 waves per SIMD: two workgroups per CU
     for name, rec in meta.items():
         assert rec["vgpr_spill_count"] == 0, (name, rec)
+
+
+def test_renderer_kernels_are_built_without_fp_contraction():
+    """Bit-exact triangle ids / identical silhouette decisions need separately rounded multiplies and adds: the two renderer
+    translation units must be compiled with -ffp-contract=off AFTER the global -ffp-contract=fast (the last flag wins)."""
+    from tssplat_amd import _build
+    for src in ("raster_kernels.hip", "aa_kernels.hip"):
+        assert src in _build.SOURCES
+        assert _build.SOURCE_FLAGS.get(src) == ["-ffp-contract=off"]
+    assert "-ffp-contract=fast" in _build.DEVICE_FLAGS                      # the energy kernels want the fused forms

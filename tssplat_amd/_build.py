@@ -30,6 +30,10 @@ HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-par
 # latency: tile kernel -0.5 % (0.4842 vs 0.4865 ms, same 79 VGPRs, no scratch; max-memory-clause and
 # -amdgpu-schedule-metric-bias=0 measured +0.2 %).
 DEVICE_FLAGS = [f"--offload-arch={ARCH}", "-ffp-contract=fast", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# The renderer kernels repeat the oracle's float32 / float64 operations one by one (bit-exact triangle ids, identical
+# silhouette decisions): a multiply and an add must round separately.  The __fmul_rn / __dmul_rn family are plain operators
+# in this toolchain's headers, so the only reliable switch is the flag (appended last: it overrides the one above).
+SOURCE_FLAGS = {"raster_kernels.hip": ["-ffp-contract=off"], "aa_kernels.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:
@@ -44,7 +48,7 @@ def _digest() -> str:
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(HOST_FLAGS + DEVICE_FLAGS).encode())
+    h.update(" ".join(HOST_FLAGS + DEVICE_FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(SOURCE_FLAGS.items())]).encode())
     return h.hexdigest()
 
 
@@ -58,7 +62,7 @@ def build_variant(name: str, extra_device_flags: list[str]) -> str:
     for src in SOURCES:
         obj = os.path.join(_OBJ, f"{os.path.splitext(src)[0]}_{name}.o")
         if src.endswith(".hip"):
-            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS + extra_device_flags
+            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS + SOURCE_FLAGS.get(src, []) + extra_device_flags
         else:
             cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
                                            os.path.join(CSRC, src), "-o", obj] + \
@@ -81,7 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(_OBJ, os.path.splitext(src)[0] + ".o")
         if src.endswith(".hip"):
-            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS
+            cmd = [hipcc, "-c", os.path.join(CSRC, src), "-o", obj] + HOST_FLAGS + DEVICE_FLAGS + SOURCE_FLAGS.get(src, [])
         else:   # host-only translation units
             cmd = [hipcc] + HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c",
                                            os.path.join(CSRC, src), "-o", obj]

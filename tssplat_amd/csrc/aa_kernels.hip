@@ -16,6 +16,10 @@
 
 #include "raster.h"
 
+// Coverage, depth and silhouette decisions repeat the oracle's operations one by one: a multiply and an add must round
+// separately.  The __fmul_rn / __dmul_rn family are plain operators in this toolchain's headers, so this file is compiled with
+// -ffp-contract=off (tssplat_amd/_build.py: SOURCE_FLAGS); tests/test_build_metadata.py checks the flag is in place.
+
 namespace tsamd {
 namespace {
 

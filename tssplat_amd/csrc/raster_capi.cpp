@@ -1,5 +1,6 @@
 // C ABI of the renderer slice (include/tssplat_amd.h, "renderer" section): stateless entry points, the caller owns
 // every buffer (positions, triangles, the depth-key workspace, outputs) and names the device by making it current.
+#include <climits>
 #include <string>
 
 #include "capi_common.h"
@@ -33,6 +34,8 @@ int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices
     if (rc) return rc;
     if (n_vertices < 0 || n_triangles < 0 || n_triangles >= (int64_t(1) << 32) - 1)
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or more than 2^32 - 2 triangles (the id shares a 64-bit key with the depth)");
+    if (batch * ((n_triangles + 255) / 256) > int64_t(INT32_MAX))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch x triangles / 256 exceeds the grid limit (2^31 - 1 workgroups)");
     const int64_t pixels = batch * int64_t(height) * width;
     if (pixels > 0 && (!workspace_dev || !rast_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "workspace_dev / rast_out_dev is null");
     if (batch * n_triangles > 0 && (!pos_clip_dev || !tri_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev is null");

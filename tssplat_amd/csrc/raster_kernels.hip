@@ -7,8 +7,10 @@
 // one by one, which is what makes the triangle ids bit-exact against it.
 //
 //   rasterize_snap_kernel  one lane per (view, vertex): window coordinates in 1/256 pixel + z/w in float64, 16 B
-//   rasterize_bin_kernel   one lane per (view, triangle): set up the three integer edge functions, walk the pixel
-//                          centres of the bounding box, 64-bit atomicMin of (depth32 << 32 | triangle) per pixel
+//   rasterize_bin_kernel   one lane per (view, triangle): integer edge functions over the pixel centres of the bounding
+//                          box in one wave-uniform loop, depth from a float32 plane, covered fragments into a per-wave
+//                          LDS queue that is drained in batches: read of the depth image, then (rarely) a 64-bit
+//                          atomicMin of (depth32 << 32 | triangle)
 //   rasterize_resolve_kernel  one lane per pixel: winning triangle -> (u, v, z/w, id + 1)
 //   interpolate_kernel / interpolate_backward_kernel  one lane per pixel
 //
@@ -18,6 +20,10 @@
 
 #include "raster.h"
 
+// Coverage, depth and silhouette decisions repeat the oracle's operations one by one: a multiply and an add must round
+// separately.  The __fmul_rn / __dmul_rn family are plain operators in this toolchain's headers, so this file is compiled with
+// -ffp-contract=off (tssplat_amd/_build.py: SOURCE_FLAGS); tests/test_build_metadata.py checks the flag is in place.
+
 namespace tsamd {
 namespace {
 
@@ -26,18 +32,19 @@ constexpr long long kSub = 1ll << kSubBits;
 constexpr long long kCoordLimit = 1ll << 22;
 constexpr unsigned long long kNoFragment = 0xFFFFFFFFFFFFFFFFull;
 
-// One snapped vertex of one view, 16 bytes: window coordinates in 1/256 pixel (|x|, |y| <= 2^22) and z/w in float64.
+// One snapped vertex of one view, 16 bytes: window coordinates in 1/256 pixel (|x|, |y| <= 2^22) and z/w rounded to float32.
 // x == kDropped: the vertex is not finite, behind the eye (w <= 0) or out of the coordinate range -- its triangles are dropped.
 struct SnapRec {
     int32_t x, y;
-    double zw;
+    float zw;
+    uint32_t pad;
 };
 static_assert(sizeof(SnapRec) == 16, "SnapRec is loaded as one 16-byte word");
 constexpr int32_t kDropped = INT32_MIN;
 
 // oracle/raster_oracle.py::snap_vertices, operation by operation (explicitly rounded double intrinsics: no contraction).
 // One lane per (view, vertex): a vertex is snapped once per view, not once per triangle that uses it (six on a closed
-// surface) -- the three float64 divisions are the expensive part of the triangle set-up.
+// surface).
 __global__ __launch_bounds__(256) void rasterize_snap_kernel(const float4 *pos, int64_t n, double width, double height, SnapRec *out)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -54,86 +61,185 @@ __global__ __launch_bounds__(256) void rasterize_snap_kernel(const float4 *pos, 
     SnapRec r;
     r.x = ok ? int32_t(X) : kDropped;
     r.y = ok ? int32_t(Y) : 0;
-    r.zw = ok ? __ddiv_rn(z, ws) : 0.0;
+    r.zw = ok ? float(__ddiv_rn(z, ws)) : 0.f;
+    r.pad = 0;
     out[gid] = r;
 }
 
 __device__ __forceinline__ bool top_left(int32_t dx, int32_t dy) { return dy < 0 || (dy == 0 && dx < 0); }
 
-// experiments (results wrong / slower): -DTSAMD_RASTER_NO_ATOMIC prices the depth-key atomics, -DTSAMD_RASTER_NO_FILTER the
-// read-before-atomic filter
-__global__ __launch_bounds__(256) void rasterize_bin_kernel(const SnapRec *snapped, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
-                                                            int64_t batch, int height, int width, unsigned long long *keys)
+// ---- fragment queue: one per wave, in LDS ----
+// The depth test of a fragment is a read of the depth image followed (rarely) by an atomic: a memory round trip that must not
+// sit inside the pixel walk.  Covered fragments are therefore appended to a small per-wave queue (key + pixel: 12 bytes) --
+// the slot comes from the wave's ballot, no atomic -- and the queue is drained whenever it could overflow and at the end,
+// four entries per lane with their four reads in flight together.
+constexpr int kQueue = 320;            // entries per wave: drained as soon as fewer than 64 are free
+constexpr int kWavesPerBlock = 4;
+
+struct WaveQueue {
+    unsigned long long *keys;          // [kQueue], this wave's slice of LDS
+    uint32_t *pixels;                  // [kQueue]
+    unsigned long long *image;         // the view's depth keys
+    int count;                         // wave-uniform
+};
+
+// read-before-atomic on the depth image: the key only ever decreases, so any value read earlier is an upper bound of the
+// current one -- a fragment that does not beat it cannot win and skips the device-scope atomic (a pixel of a scene with depth
+// complexity d sees ~ln d improvements)
+__device__ __forceinline__ void drain(WaveQueue &q, int lane)
 {
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= batch * n_tri) return;
-    const int64_t b = gid / n_tri, t = gid - b * n_tri;
-    const int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) return;
-    const SnapRec *sv = snapped + b * n_vertices;
-    const SnapRec s0 = sv[i0];
-    SnapRec s1 = sv[i1], s2 = sv[i2];
-    if (s0.x == kDropped || s1.x == kDropped || s2.x == kDropped) return;
-    const long long area = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s1.y - s0.y) * (s2.x - s0.x);
-    if (area == 0) return;
-    if (area < 0) {   // orient counter-clockwise
-        const SnapRec tmp = s1;
-        s1 = s2;
-        s2 = tmp;
+    for (int base = 0; base < q.count; base += 4 * 64) {
+        unsigned long long key[4], cur[4];
+        unsigned long long *slot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = base + 64 * j + lane;
+            const bool have = k < q.count;
+            key[j] = have ? q.keys[have ? k : 0] : kNoFragment;
+            slot[j] = q.image + (have ? q.pixels[k] : uint32_t(lane));   // (an empty lane reads a harmless pixel: the load stays unconditional)
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (key[j] < cur[j]) atomicMin(slot[j], key[j]);              // (an empty lane's key is all ones: never smaller)
     }
-    const int32_t minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
-    const int32_t miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
-    // pixel i has its centre at i * 256 + 128; >> is an arithmetic shift (floor) on negative values
+    q.count = 0;
+}
+
+struct DepthPlane {   // z/w = z0 + zx (x - x0) + zy (y - y0), float32
+    float z0, zx, zy;
+    int32_t x0, y0;
+};
+
+// The pixel walk of a wave: every lane steps through the pixel centres of its triangle's bounding box, one candidate per
+// iteration of ONE wave-uniform loop (not a loop nest per lane: the wave runs max(candidates) iterations, not max(rows) x
+// max(columns)).  Edge functions E_k (edge opposite vertex k, >= 0 inside) in 32-bit integers when the triangle is small enough
+// for every value to fit (|edge vector| < 2^14 sub-pixel units = 64 pixels: |E| < 2^30), in 64-bit integers otherwise -- the same
+// integers either way.  The top-left rule is folded into the start values (an edge that does not own its boundary starts one
+// lower), so "inside" is one sign test of the three values OR-ed together.
+template <class Int>
+__device__ __forceinline__ void wave_walk(bool mine, int32_t px0, int32_t px1, int32_t py0, int32_t py1, Int r0, Int r1, Int r2, Int sx0, Int sx1, Int sx2,
+                                          Int sy0, Int sy1, Int sy2, const DepthPlane pl, unsigned long long tid, int width, int lane, WaveQueue &q)
+{
     const int32_t hs = int32_t(kSub / 2);
-    const int32_t px0 = max(0, (minx - hs + int32_t(kSub) - 1) >> kSubBits), px1 = min(width - 1, (maxx - hs) >> kSubBits);
-    const int32_t py0 = max(0, (miny - hs + int32_t(kSub) - 1) >> kSubBits), py1 = min(height - 1, (maxy - hs) >> kSubBits);
-    if (px0 > px1 || py0 > py1) return;   // no pixel centre inside the bounding box: most triangles of a dense surface end here
-    // E_k = edge function of the edge opposite vertex k, >= 0 inside; d/dx = -(dy) * 256 per pixel, d/dy = dx * 256
-    const int32_t dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
-    const bool tl0 = top_left(dx0, dy0), tl1 = top_left(dx1, dy1), tl2 = top_left(dx2, dy2);
-    const int32_t cx0 = px0 * int32_t(kSub) + hs, cy0 = py0 * int32_t(kSub) + hs;
-    long long r0 = (long long)dx0 * (cy0 - s1.y) - (long long)dy0 * (cx0 - s1.x);
-    long long r1 = (long long)dx1 * (cy0 - s2.y) - (long long)dy1 * (cx0 - s2.x);
-    long long r2 = (long long)dx2 * (cy0 - s0.y) - (long long)dy2 * (cx0 - s0.x);
-    const long long sx0 = (long long)dy0 * kSub, sx1 = (long long)dy1 * kSub, sx2 = (long long)dy2 * kSub;
-    const long long sy0 = (long long)dx0 * kSub, sy1 = (long long)dx1 * kSub, sy2 = (long long)dx2 * kSub;
-    unsigned long long *kb = keys + size_t(b) * size_t(height) * size_t(width);
-    for (int32_t py = py0; py <= py1; ++py) {
-        long long e0 = r0, e1 = r1, e2 = r2;
-        for (int32_t px = px0; px <= px1; ++px) {
-            const bool in = (e0 > 0 || (e0 == 0 && tl0)) && (e1 > 0 || (e1 == 0 && tl1)) && (e2 > 0 || (e2 == 0 && tl2));
+    int32_t px = px0, py = py0;
+    Int e0 = r0, e1 = r1, e2 = r2;
+    bool active = mine;
+    while (__ballot(active) != 0ull) {
+        bool in = active && (e0 | e1 | e2) >= 0;
+        unsigned long long key = 0;
+        if (in) {
+            // oracle/raster_oracle.py::rasterize_ids, operation by operation (this file is compiled without contraction)
+            const float zw = (pl.z0 + pl.zx * float(px * int32_t(kSub) + hs - pl.x0)) + pl.zy * float(py * int32_t(kSub) + hs - pl.y0);
+            in = zw >= -1.f && zw <= 1.f;
+            const float s = (zw + 1.f) * 2147483648.f;                       // in [0, 2^32]: the scaling is exact
+            const uint32_t depth = s >= 4294967296.f ? 0xFFFFFFFFu : uint32_t(s);
+            key = ((unsigned long long)depth << 32) | tid;
+        }
+        const unsigned long long mask = __ballot(in);
+        if (mask != 0ull) {
             if (in) {
-                // z/w by the integer edge functions as weights: oracle/raster_oracle.py::rasterize_ids, operation by operation
-                // (a depth plane set up per triangle was measured slower here: 2.10 vs 1.86 ms, most triangles of the scene
-                // produce at most one fragment and the two divisions of the set-up are paid by every triangle with a bounding box)
-                const double a = double((e0 + e1) + e2);
-                const double num = __dadd_rn(__dadd_rn(__dmul_rn(double(e0), s0.zw), __dmul_rn(double(e1), s1.zw)), __dmul_rn(double(e2), s2.zw));
-                const double zw = __ddiv_rn(num, a);
-                if (zw >= -1.0 && zw <= 1.0) {
-                    double q = floor(__dmul_rn(__dadd_rn(zw, 1.0), 2147483648.0));
-                    q = q < 0.0 ? 0.0 : (q > 4294967295.0 ? 4294967295.0 : q);
-                    const unsigned long long key = ((unsigned long long)q << 32) | (unsigned long long)t;
-                    unsigned long long *slot = kb + size_t(py) * size_t(width) + size_t(px);
-#if defined(TSAMD_RASTER_NO_ATOMIC)
-                    if (key == 1) *slot = key;
-#elif defined(TSAMD_RASTER_NO_FILTER)
-                    atomicMin(slot, key);
-#else
-                    // the key only ever decreases, so any value read earlier is an upper bound of the current one: a
-                    // fragment that does not beat it cannot win and skips the device-scope atomic (most do: a pixel of a
-                    // scene with depth complexity d sees ~ln d improvements)
-                    if (key < __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(slot, key);
-#endif
-                }
+                const int at = q.count + int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)));
+                q.keys[at] = key;
+                q.pixels[at] = uint32_t(py) * uint32_t(width) + uint32_t(px);
             }
+            q.count += __popcll(mask);
+            if (q.count > kQueue - 64) drain(q, lane);
+        }
+        if (active) {
+            ++px;
             e0 -= sx0;
             e1 -= sx1;
             e2 -= sx2;
+            if (px > px1) {
+                px = px0;
+                ++py;
+                r0 += sy0;
+                r1 += sy1;
+                r2 += sy2;
+                e0 = r0;
+                e1 = r1;
+                e2 = r2;
+                active = py <= py1;
+            }
         }
-        r0 += sy0;
-        r1 += sy1;
-        r2 += sy2;
     }
+}
+
+// One lane per (view, triangle); a workgroup is four independent waves (no barrier anywhere).
+__global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(const SnapRec *snapped, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
+                                                                             int blocks_per_view, int height, int width, unsigned long long *keys)
+{
+    __shared__ unsigned long long queue_keys[kWavesPerBlock * kQueue];
+    __shared__ uint32_t queue_pixels[kWavesPerBlock * kQueue];
+    const int b = int(blockIdx.x) / blocks_per_view;
+    const int64_t t = int64_t(int(blockIdx.x) - b * blocks_per_view) * (64 * kWavesPerBlock) + threadIdx.x;
+    const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
+    WaveQueue q;
+    q.keys = queue_keys + wave * kQueue;
+    q.pixels = queue_pixels + wave * kQueue;
+    q.image = keys + size_t(b) * size_t(height) * size_t(width);
+    q.count = 0;
+
+    // ---- triangle set-up ----
+    bool valid = t < n_tri;
+    int32_t i0 = 0, i1 = 0, i2 = 0;
+    if (valid) {
+        i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices);
+    }
+    SnapRec s0 = {}, s1 = {}, s2 = {};
+    if (valid) {
+        const SnapRec *sv = snapped + int64_t(b) * n_vertices;
+        s0 = sv[i0], s1 = sv[i1], s2 = sv[i2];
+        valid = !(s0.x == kDropped || s1.x == kDropped || s2.x == kDropped);
+    }
+    long long area = 0;
+    int32_t px0 = 0, px1 = -1, py0 = 0, py1 = -1;
+    const int32_t hs = int32_t(kSub / 2);
+    if (valid) {
+        area = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s1.y - s0.y) * (s2.x - s0.x);
+        if (area < 0) {   // orient counter-clockwise
+            const SnapRec tmp = s1;
+            s1 = s2;
+            s2 = tmp;
+        }
+        const int32_t minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
+        const int32_t miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
+        // pixel i has its centre at i * 256 + 128; >> is an arithmetic shift (floor) on negative values
+        px0 = max(0, (minx - hs + int32_t(kSub) - 1) >> kSubBits), px1 = min(width - 1, (maxx - hs) >> kSubBits);
+        py0 = max(0, (miny - hs + int32_t(kSub) - 1) >> kSubBits), py1 = min(height - 1, (maxy - hs) >> kSubBits);
+        valid = area != 0 && px0 <= px1 && py0 <= py1;   // no pixel centre inside the bounding box: nothing to do
+    }
+    // depth plane through the snapped vertices, float32, every operation rounded on its own (oracle/raster_oracle.py::rasterize_ids)
+    DepthPlane pl;
+    {
+        const float A = float(double(area < 0 ? -area : area));
+        const float d1 = s1.zw - s0.zw, d2 = s2.zw - s0.zw;
+        pl.zx = (d1 * float(s2.y - s0.y) - d2 * float(s1.y - s0.y)) / A;
+        pl.zy = (d2 * float(s1.x - s0.x) - d1 * float(s2.x - s0.x)) / A;
+        pl.z0 = s0.zw;
+        pl.x0 = s0.x;
+        pl.y0 = s0.y;
+    }
+    // E_k: d/dx = -(dy) * 256 per pixel, d/dy = dx * 256; an edge that is not top-left starts one lower
+    const int32_t dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
+    const int32_t b0 = top_left(dx0, dy0) ? 0 : 1, b1 = top_left(dx1, dy1) ? 0 : 1, b2 = top_left(dx2, dy2) ? 0 : 1;
+    const int32_t cx0 = px0 * int32_t(kSub) + hs, cy0 = py0 * int32_t(kSub) + hs;
+    const int32_t reach = max(max(abs(dx0), abs(dy0)), max(max(abs(dx1), abs(dy1)), max(abs(dx2), abs(dy2))));
+    const bool small = reach < (1 << 14);
+    // |c - v| <= reach + 256 for every pixel centre of the bounding box, so |E| < 2 * 2^14 * (2^14 + 2^8) < 2^30 for a small triangle
+    wave_walk<int32_t>(valid && small, px0, px1, py0, py1, dx0 * (cy0 - s1.y) - dy0 * (cx0 - s1.x) - b0, dx1 * (cy0 - s2.y) - dy1 * (cx0 - s2.x) - b1,
+                       dx2 * (cy0 - s0.y) - dy2 * (cx0 - s0.x) - b2, dy0 * int32_t(kSub), dy1 * int32_t(kSub), dy2 * int32_t(kSub), dx0 * int32_t(kSub),
+                       dx1 * int32_t(kSub), dx2 * int32_t(kSub), pl, (unsigned long long)t, width, lane, q);
+    if (__ballot(valid && !small) != 0ull)
+        wave_walk<long long>(valid && !small, px0, px1, py0, py1, (long long)dx0 * (cy0 - s1.y) - (long long)dy0 * (cx0 - s1.x) - b0,
+                             (long long)dx1 * (cy0 - s2.y) - (long long)dy1 * (cx0 - s2.x) - b1,
+                             (long long)dx2 * (cy0 - s0.y) - (long long)dy2 * (cx0 - s0.x) - b2, (long long)dy0 * kSub, (long long)dy1 * kSub,
+                             (long long)dy2 * kSub, (long long)dx0 * kSub, (long long)dx1 * kSub, (long long)dx2 * kSub, pl, (unsigned long long)t, width,
+                             lane, q);
+    drain(q, lane);
 }
 
 // nvdiffrast's fragment stage: barycentrics from the UNSNAPPED clip-space positions (homogeneous 2-D edge functions),
@@ -281,8 +387,9 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
         hipLaunchKernelGGL(rasterize_snap_kernel, dim3(blocks_for(batch * n_vertices)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip),
                            batch * n_vertices, double(width), double(height), snapped);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(blocks_for(batch * n_tri)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri, batch, height,
-                           width, keys);
+        const int64_t blocks_per_view = (n_tri + 255) / 256;   // (256 = 64 * kWavesPerBlock triangles per workgroup)
+        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(unsigned(batch * blocks_per_view)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri,
+                           int(blocks_per_view), height, width, keys);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
