@@ -72,7 +72,7 @@ __device__ __forceinline__ bool top_left(int32_t dx, int32_t dy) { return dy < 0
 // The depth test of a fragment is a read of the depth image followed (rarely) by an atomic: a memory round trip that must not
 // sit inside the pixel walk.  Covered fragments are therefore appended to a small per-wave queue (key + pixel: 12 bytes) --
 // the slot comes from the wave's ballot, no atomic -- and the queue is drained whenever it could overflow and at the end,
-// four entries per lane with their four reads in flight together.
+// three entries per lane with their three reads in flight together (a fourth costs the eighth wave per SIMD: 70 instead of 64 VGPRs).
 constexpr int kQueue = 320;            // entries per wave: drained as soon as fewer than 64 are free
 constexpr int kWavesPerBlock = 4;
 
@@ -88,20 +88,20 @@ struct WaveQueue {
 // complexity d sees ~ln d improvements)
 __device__ __forceinline__ void drain(WaveQueue &q, int lane)
 {
-    for (int base = 0; base < q.count; base += 4 * 64) {
-        unsigned long long key[4], cur[4];
-        unsigned long long *slot[4];
+    for (int base = 0; base < q.count; base += 3 * 64) {
+        unsigned long long key[3], cur[3];
+        unsigned long long *slot[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 3; ++j) {
             const int k = base + 64 * j + lane;
             const bool have = k < q.count;
             key[j] = have ? q.keys[have ? k : 0] : kNoFragment;
             slot[j] = q.image + (have ? q.pixels[k] : uint32_t(lane));   // (an empty lane reads a harmless pixel: the load stays unconditional)
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 3; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 3; ++j)
             if (key[j] < cur[j]) atomicMin(slot[j], key[j]);              // (an empty lane's key is all ones: never smaller)
     }
     q.count = 0;
