@@ -30,6 +30,10 @@ python bench.py --gpus 2 --dist-backend gloo --all-ranks-on-device0 --steps 20 -
 # renderer slice: kernel stats of the raster bench
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_raster -- python $R/tools/bench_raster.py --reps 5 > $OUT/stats_raster.log 2>&1)
 python tools/bench_raster.py > $OUT/bench_raster.json 2> $OUT/bench_raster.log
+python tools/bench_raster.py --spheres 64 > $OUT/bench_raster64.json 2>> $OUT/bench_raster.log
+# the reference's inner loop (geometry + renderer + optimiser) on the headline scene and on a single object
+python tools/bench_pipeline.py > $OUT/pipeline_512.json 2> $OUT/pipeline.log
+python tools/bench_pipeline.py --spheres 1 > $OUT/pipeline_1.json 2>> $OUT/pipeline.log
 # per-phase shader-clock stamps and stage ablations of the tile kernel (ablation build), two and one workgroups per CU
 python tools/ablate.py --spheres 512 --reps 10 > $OUT/ablate_512.log 2>&1
 python tools/ablate.py --spheres 512 --reps 5 --masks 0 --lds-request 100000 > $OUT/ablate_512_1wg.log 2>&1

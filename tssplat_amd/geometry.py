@@ -187,3 +187,65 @@ def permute_surface_v(tet_v: torch.Tensor, surface_vid: torch.Tensor, dev: float
         idx = surface_vid.long()
         noise = torch.rand((idx.shape[0], tet_v.shape[1]), device=tet_v.device, dtype=tet_v.dtype, generator=generator)
         tet_v[idx] += noise * dev - dev * 0.5
+
+
+class TetMeshGeometry(torch.nn.Module):
+    """Mirror of ``TetMeshGeometry`` (geometry/tetmesh_geometry.py:118-193) for the per-iteration path: the parameter ``tet_v``,
+    the index buffers, ``mesh_smooth_barrier`` and ``forward(iter_num, **kwargs) -> TetMeshGeometryForwardData`` with the
+    reference's surface permutation (:176-182) and energy schedule (:184-189).
+
+    The reference reads its configuration with omegaconf and its mesh with pypgo (``TetrahedronMesh(veg_file_path=...)``);
+    neither is part of the hot path, so the constructor takes the arrays (``from_veg`` reads a ``.veg`` file with this
+    package's own reader) and the reference's ``Config`` fields as keyword arguments.  Remeshing / export / uv are not
+    mirrored (offline tools)."""
+
+    def __init__(self, vtx_init, elem, use_smooth_barrier: bool = True, smooth_barrier_param=None, optimize_geo: bool = True,
+                 device=None, surface_vid=None, surface_fid=None, **energy_kwargs):
+        super().__init__()
+        self.device = torch.device("cuda" if device is None else device)
+        if self.device.type != "cuda":
+            raise RuntimeError("tssplat_amd.geometry.TetMeshGeometry needs a GPU device (there is no CPU fallback)")
+        vtx = np.ascontiguousarray(np.asarray(vtx_init, dtype=np.float32).reshape(-1, 3))
+        elem = np.ascontiguousarray(np.asarray(elem, dtype=np.int32).reshape(-1, 4))
+        if surface_vid is None or surface_fid is None:
+            surface_vid, surface_fid = get_surface_vf(elem)            # geometry/tetrahedron_mesh.py: the one-off boundary extraction
+        tet_v = torch.from_numpy(vtx).to(self.device)
+        if optimize_geo:                                                # tetmesh_geometry.py:138-141
+            self.tet_v = torch.nn.Parameter(tet_v, requires_grad=True)
+        else:
+            self.register_buffer("tet_v", tet_v)
+        self.tet_elem = torch.from_numpy(elem).to(self.device)
+        self.surface_vid = torch.from_numpy(np.ascontiguousarray(np.asarray(surface_vid, dtype=np.int32))).to(self.device)
+        self.surface_fid = torch.from_numpy(np.ascontiguousarray(np.asarray(surface_fid, dtype=np.int32).reshape(-1, 3))).to(self.device)
+        self.use_smooth_barrier = bool(use_smooth_barrier)
+        self.mesh_smooth_barrier = None
+        if self.use_smooth_barrier:                                     # tetmesh_geometry.py:156-162
+            from .energies import SmoothnessBarrierEnergy
+            for key in ("smooth_eng_coeff", "barrier_coeff", "increase_order_iter"):
+                if not hasattr(smooth_barrier_param, key) and not (isinstance(smooth_barrier_param, dict) and key in smooth_barrier_param):
+                    raise ValueError(f"smooth_barrier_param needs {key!r} (config/gso.yaml:8-11)")
+            flags = smooth_barrier_param
+            if isinstance(flags, dict):
+                import types
+                flags = types.SimpleNamespace(**flags)
+            with torch.cuda.device(self.device):
+                self.mesh_smooth_barrier = SmoothnessBarrierEnergy(vtx, elem, flags, **energy_kwargs)
+        self._surface_ops = _ops_for(self.surface_vid, self.surface_fid, int(tet_v.shape[0]))
+
+    @classmethod
+    def from_veg(cls, path, **kwargs):
+        from . import scenes
+        v, t = scenes.read_veg(path)
+        return cls(v, t, **kwargs)
+
+    def forward(self, iter_num, **kwargs):
+        if "permute_surface_v" in kwargs:                               # tetmesh_geometry.py:176-182
+            assert "permute_surface_v_dev" in kwargs
+            permute_surface_v(self.tet_v.data if isinstance(self.tet_v, torch.nn.Parameter) else self.tet_v, self.surface_vid,
+                              float(kwargs["permute_surface_v_dev"]))
+        smooth_barrier_energy = None
+        if self.use_smooth_barrier:                                     # tetmesh_geometry.py:184-189
+            smooth_coeff, barrier_coeff = self.mesh_smooth_barrier.coeff_scheduler(iter_num)
+            smooth_barrier_energy = self.mesh_smooth_barrier(self.tet_v, iter_num, smooth_coeff, barrier_coeff)
+        return TetMeshGeometryForwardData(self.tet_v, self.tet_elem, self.surface_vid, self.surface_fid, smooth_barrier_energy,
+                                          surface_ops=self._surface_ops)
