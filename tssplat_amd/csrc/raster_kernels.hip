@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(cons
     __shared__ unsigned long long queue_keys[kWavesPerBlock * kQueue];
     __shared__ uint32_t queue_pixels[kWavesPerBlock * kQueue];
     const int b = int(blockIdx.x) / blocks_per_view;
-    const int64_t t = int64_t(int(blockIdx.x) - b * blocks_per_view) * (64 * kWavesPerBlock) + threadIdx.x;
+    const int64_t t_own = int64_t(int(blockIdx.x) - b * blocks_per_view) * (64 * kWavesPerBlock) + threadIdx.x;
     const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
     WaveQueue q;
     q.keys = queue_keys + wave * kQueue;
@@ -182,7 +182,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(cons
     q.image = keys + size_t(b) * size_t(height) * size_t(width);
     q.count = 0;
 
-    // ---- triangle set-up ----
+    // ---- triangle fetch ----
+    const int32_t hs = int32_t(kSub / 2);
+    const int64_t t = t_own;
     bool valid = t < n_tri;
     int32_t i0 = 0, i1 = 0, i2 = 0;
     if (valid) {
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(cons
         s0 = sv[i0], s1 = sv[i1], s2 = sv[i2];
         valid = !(s0.x == kDropped || s1.x == kDropped || s2.x == kDropped);
     }
+    // ---- triangle set-up ----
     long long area = 0;
     int32_t px0 = 0, px1 = -1, py0 = 0, py1 = -1;
-    const int32_t hs = int32_t(kSub / 2);
     if (valid) {
         area = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s1.y - s0.y) * (s2.x - s0.x);
         if (area < 0) {   // orient counter-clockwise

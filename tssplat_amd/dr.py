@@ -18,6 +18,8 @@ rejected; no polygon clipping (a triangle with a vertex at ``w <= 0`` is dropped
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _capi
@@ -157,7 +159,6 @@ class TopologyHash:
             raise RuntimeError("tssplat_amd.dr: tri must be a GPU tensor (there is no CPU fallback)")
         T = int(tri.shape[0])
         self.n_triangles = T
-        self.key = (tri.data_ptr(), tri._version, T, tri.device)
         self.opp = torch.empty(3 * T, dtype=torch.int32, device=tri.device)
         need = int(_lib.tsamd_antialias_topology_workspace_bytes(T))
         if need < 0:
@@ -175,14 +176,17 @@ _last_topology: dict = {}
 
 
 def _topology_for(tri: torch.Tensor) -> TopologyHash:
-    """``topology_hash=None``: nvdiffrast rebuilds the table on every call; the last one per device is kept here as long as
-    the same (unmodified) index tensor comes back."""
-    key = (tri.data_ptr(), tri._version, int(tri.shape[0]), tri.device)
+    """``topology_hash=None``: nvdiffrast rebuilds the table on every call; the last one per device is kept here for as long as
+    the SAME (alive, unmodified) index tensor comes back -- identity through a weak reference plus the version counter, not
+    the address: a freed tensor whose storage a new one reuses can never be served the old table."""
     hit = _last_topology.get(tri.device)
-    if hit is None or hit.key != key:
-        hit = TopologyHash(tri)
-        _last_topology[tri.device] = hit
-    return hit
+    if hit is not None:
+        topo, ref, version = hit
+        if ref() is tri and version == tri._version:
+            return topo
+    topo = TopologyHash(tri)
+    _last_topology[tri.device] = (topo, weakref.ref(tri), tri._version)
+    return topo
 
 
 class _AntialiasFunc(torch.autograd.Function):
