@@ -26,8 +26,15 @@ def test_tile_kernels_have_no_static_lds_and_do_not_spill():
         assert rec["vgpr_spill_count"] == 0 and rec["private_segment_fixed_size"] == 0, (name, rec)
     default = [v for k, v in tiles.items() if "ILb1ELi768ELi6ELb0ELb0E" in k]
     assert len(default) == 1 and default[0]["vgpr_count"] <= 80, default      # 6 waves per SIMD: two workgroups per CU
-    for name, rec in meta.items():
-        assert rec["vgpr_spill_count"] == 0, (name, rec)
+    for name, rec in meta.items():                                          # every kernel of every translation unit
+        assert rec["vgpr_spill_count"] == 0 and rec["private_segment_fixed_size"] == 0, (name, rec)
+    # the streaming kernels address LDS absolutely too
+    tubes = {k: v for k, v in meta.items() if "stream_tube_kernel" in k}
+    assert len(tubes) == 2 and all(v["group_segment_fixed_size"] == 0 for v in tubes.values()), tubes
+    # the rasteriser's pixel walk is sized for eight waves per SIMD (drain(): three reads in flight, not four)
+    bins = [v for k, v in meta.items() if "rasterize_bin_kernel" in k]
+    assert len(bins) == 1 and bins[0]["vgpr_count"] <= 64, bins
+    assert len(meta) >= 30                                                  # all bundles of .hip_fatbin were read, not just the first
 
 
 def test_renderer_kernels_are_built_without_fp_contraction():

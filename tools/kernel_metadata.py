@@ -18,23 +18,33 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
 def kernel_metadata(lib: str) -> dict[str, dict[str, int]]:
-    with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "co.elf")
-        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(d, "copy.so")])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
-        notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    """Every kernel of every translation unit: .hip_fatbin holds one offload bundle per .hip file, back to back."""
     out: dict[str, dict[str, int]] = {}
-    for block in notes.split("  - .agpr_count:")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", block).group(1)
-        rec = {}
-        for key in ("group_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count",
-                    "private_segment_fixed_size", "max_flat_workgroup_size"):
-            m = re.search(r"\." + key + r":\s+(\d+)", block)
-            if m:
-                rec[key] = int(m.group(1))
-        out[name] = rec
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", lib, os.path.join(d, "copy.so")])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), blob)]
+        for k, a in enumerate(starts):
+            part, co = os.path.join(d, f"bundle{k}.bin"), os.path.join(d, f"co{k}.elf")
+            with open(part, "wb") as fh:
+                fh.write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+            subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={part}",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+            for block in notes.split("  - .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", block).group(1)
+                rec = {}
+                for key in ("group_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count",
+                            "private_segment_fixed_size", "max_flat_workgroup_size"):
+                    m = re.search(r"\." + key + r":\s+(\d+)", block)
+                    if m:
+                        rec[key] = int(m.group(1))
+                out[name] = rec
     return out
 
 
