@@ -187,6 +187,21 @@ int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream);
 void tsamd_graph_destroy(tsamd_graph *graph);
 
 /* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
+/* n_iters optimisation steps as ONE HIP graph: per step the evaluation above (energy into energy_ring_dev[k], gradient into
+ * grad_dev, upstream gradient 1) followed by tsamd_adam_uniform_step on param_dev with that gradient -- the sequence
+ * loss.backward(); optimizer.step() of /root/reference/trainer.py:130-133 for a loss that is the energy alone, with nothing on
+ * the host between the steps.  The pointers are baked in (param_dev [n_vertices, 3] is read and updated in place; g1_dev /
+ * g2_dev are the optimiser's moments; workspace_dev: tsamd_train_loop_workspace_bytes(n_iters)).  A launch takes the schedule of
+ * its n_iters steps -- c1[k], c2[k], order[k] (energies/smooth_barrier.py:47-63), the optimiser's step number of the first one
+ * (first_step >= 1: bias corrections 1 - beta^step as in tsamd_adam_uniform_step) and optionally grad_limit[k] (NULL or < 0:
+ * none) -- as kernel-node arguments.  Same single-stream rule as the handle; the handle must outlive the loop. */
+typedef struct tsamd_train_loop tsamd_train_loop;
+int64_t tsamd_train_loop_workspace_bytes(int32_t n_iters);
+int tsamd_train_loop_create(tsamd_handle *h, float *param_dev, float *grad_dev, float *g1_dev, float *g2_dev, float *energy_ring_dev,
+                            void *workspace_dev, int32_t n_iters, tsamd_train_loop **out);
+int tsamd_train_loop_launch(tsamd_train_loop *loop, const float *c1, const float *c2, const int32_t *order, float lr, float beta1, float beta2,
+                            int64_t first_step, const float *grad_limit, void *stream);
+void tsamd_train_loop_destroy(tsamd_train_loop *loop);
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 
 /*

@@ -638,3 +638,53 @@ def test_compiled_c_consumer_on_device(tmp_path):
     print(out.stdout)
     assert out.returncode == 0, f"exit {out.returncode}: {out.stdout[-2000:]} {out.stderr[-2000:]}"
     assert "abi device ok" in out.stdout
+
+
+def test_fused_train_loop_equals_eager(ext):
+    """``FusedEnergyAdamLoop``: n iterations of ``energy(x, it, *coeff_scheduler(it)).backward(); optimizer.step()``
+    (/root/reference/trainer.py:130-133 for a loss that is the energy alone) replayed from ONE graph launch give the same
+    parameters, moments, energies and optimiser counters as the eager loop -- bit for bit: the same kernels on the same inputs.
+    Crosses the order switch (increase_order_iter) and a grad_limit stage boundary."""
+    from tssplat_amd import scenes
+    from tssplat_amd.energies import FusedEnergyAdamLoop, SmoothnessBarrierEnergy
+    from tssplat_amd.utils.optimizer import AdamUniform
+
+    class Flags:
+        smooth_eng_coeff = 2e-4
+        barrier_coeff = 2e-4
+        increase_order_iter = 10
+
+    sc = scenes.make_scene("kuhn8", 6)
+    x0 = torch.from_numpy(scenes.deform(sc, 0.25)).cuda()
+    kw = dict(lr=0.05, grad_limit=True, grad_limit_values=[0.01, 0.004], grad_limit_iters=[13])
+    # eager
+    mod_e = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    xe = torch.nn.Parameter(x0.clone())
+    opt_e = AdamUniform([xe], **kw)
+    energies_e = []
+    for it in range(24):
+        c1, c2 = mod_e.coeff_scheduler(it)
+        opt_e.zero_grad()
+        e = mod_e(xe, it, c1, c2)
+        e.backward()
+        opt_e.step()
+        energies_e.append(float(e.detach()))
+    # fused: three launches of eight iterations
+    mod_f = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    xf = torch.nn.Parameter(x0.clone())
+    opt_f = AdamUniform([xf], **kw)
+    loop = FusedEnergyAdamLoop(mod_f, xf, opt_f, n_iters=8)
+    energies_f = []
+    for first in (0, 8, 16):
+        energies_f += loop.run(first).cpu().tolist()
+    assert energies_f == energies_e
+    assert torch.equal(xf.data, xe.data)
+    assert torch.equal(opt_f.state[xf]["g1"], opt_e.state[xe]["g1"]) and torch.equal(opt_f.state[xf]["g2"], opt_e.state[xe]["g2"])
+    assert (opt_f.state[xf]["step"], opt_f.cc, opt_f.grad_limit_ptr) == (opt_e.state[xe]["step"], opt_e.cc, opt_e.grad_limit_ptr) == (24, 24, 1)
+    assert float((xf.data - x0).abs().max()) > 1e-3                          # the loop went somewhere (24 limited steps)
+    # the optimiser's moments are baked into the graph: replacing them must be refused, not silently ignored
+    opt_f.reset()
+    with pytest.raises(RuntimeError, match="moment tensors were replaced"):
+        loop.run(24)
+    with pytest.raises(RuntimeError, match="exactly the parameter"):
+        FusedEnergyAdamLoop(mod_f, xf, AdamUniform([xf, torch.nn.Parameter(x0.clone())]), n_iters=2)

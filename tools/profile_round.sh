@@ -34,6 +34,9 @@ python tools/bench_raster.py --spheres 64 > $OUT/bench_raster64.json 2>> $OUT/be
 # the reference's inner loop (geometry + renderer + optimiser) on the headline scene and on a single object
 python tools/bench_pipeline.py > $OUT/pipeline_512.json 2> $OUT/pipeline.log
 python tools/bench_pipeline.py --spheres 1 > $OUT/pipeline_1.json 2>> $OUT/pipeline.log
+for cfg in "kuhn8 64" "kuhn8 256"; do set -- $cfg
+  python tools/bench_train_loop.py --scene $1 --spheres $2 > $OUT/train_loop_$1x$2.json 2>> $OUT/pipeline.log
+done
 # per-phase shader-clock stamps and stage ablations of the tile kernel (ablation build), two and one workgroups per CU
 python tools/ablate.py --spheres 512 --reps 10 > $OUT/ablate_512.log 2>&1
 python tools/ablate.py --spheres 512 --reps 5 --masks 0 --lds-request 100000 > $OUT/ablate_512_1wg.log 2>&1

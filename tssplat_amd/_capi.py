@@ -123,6 +123,12 @@ SIGNATURES = {
     "tsamd_stream_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_stream_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_stream_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
+    "tsamd_train_loop_workspace_bytes": (C.c_int64, [C.c_int32]),
+    "tsamd_train_loop_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.POINTER(C.c_void_p)]),
+    "tsamd_train_loop_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_float, C.c_float,
+                                          C.c_float, C.c_int64, C.POINTER(C.c_float), C.c_void_p]),
+    "tsamd_train_loop_destroy": (None, [C.c_void_p]),
     # renderer slice
     "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     "tsamd_rasterize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -430,6 +430,71 @@ void tsamd_graph_destroy(tsamd_graph *graph)
     delete graph;
 }
 
+struct tsamd_train_loop {
+    tsamd::TrainLoopGraph *g = nullptr;
+    int device = 0;
+    int n_iters = 0;
+    std::vector<tsamd::TrainLoopStep> steps;
+};
+
+int64_t tsamd_train_loop_workspace_bytes(int32_t n_iters) { return n_iters < 1 ? -1 : int64_t(n_iters) * 8; }
+
+int tsamd_train_loop_create(tsamd_handle *h, float *param_dev, float *grad_dev, float *g1_dev, float *g2_dev, float *energy_ring_dev,
+                            void *workspace_dev, int32_t n_iters, tsamd_train_loop **out)
+{
+    if (!out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    int rc = check_eval(h, param_dev);
+    if (rc) return rc;
+    if (!grad_dev || !g1_dev || !g2_dev || !energy_ring_dev || !workspace_dev) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (n_iters < 1 || n_iters > 4096) return fail(TSAMD_ERR_INVALID_ARGUMENT, "n_iters out of range (1 .. 4096)");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(h->device));
+    const tsamd::EvalArgs a = eval_args(h, param_dev, nullptr, 0.f, 0.f, 2, energy_ring_dev, grad_dev, nullptr);
+    tsamd::TrainLoopGraph *tg = nullptr;
+    TSAMD_HIP(tsamd::train_loop_create(a, param_dev, g1_dev, g2_dev, 3 * h->plan.n, workspace_dev, n_iters, &tg));
+    tsamd_train_loop *w = new (std::nothrow) tsamd_train_loop();
+    if (!w) {
+        tsamd::train_loop_destroy(tg);
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
+    }
+    w->g = tg;
+    w->device = h->device;
+    w->n_iters = n_iters;
+    w->steps.resize(size_t(n_iters));
+    *out = w;
+    return TSAMD_OK;
+}
+
+int tsamd_train_loop_launch(tsamd_train_loop *loop, const float *c1, const float *c2, const int32_t *order, float lr, float beta1, float beta2,
+                            int64_t first_step, const float *grad_limit, void *stream)
+{
+    if (!loop || !loop->g) return fail(TSAMD_ERR_INVALID_ARGUMENT, "loop is null");
+    if (!c1 || !c2 || !order || first_step < 1) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null schedule or first_step < 1");
+    for (int k = 0; k < loop->n_iters; ++k) {
+        tsamd::TrainLoopStep &s = loop->steps[size_t(k)];
+        s.c1 = c1[k];
+        s.c2 = c2[k];
+        s.order = order[k];
+        s.bias1 = float(1.0 - std::pow(double(beta1), double(first_step + k)));   // as tsamd_adam_uniform_step (optimizer.py:67-68)
+        s.bias2 = float(1.0 - std::pow(double(beta2), double(first_step + k)));
+        s.limit = grad_limit ? grad_limit[k] : -1.f;
+    }
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(loop->device));
+    TSAMD_HIP(tsamd::train_loop_launch(loop->g, loop->steps.data(), lr, beta1, beta2, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+void tsamd_train_loop_destroy(tsamd_train_loop *loop)
+{
+    if (!loop) return;
+    DeviceGuard g;
+    (void)g.enter(loop->device);
+    tsamd::train_loop_destroy(loop->g);
+    delete loop;
+}
+
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
 {
     if (!h || !terms_host2) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");

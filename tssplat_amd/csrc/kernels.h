@@ -43,6 +43,19 @@ struct EvalGraph;
 hipError_t eval_graph_create(const EvalArgs &a, EvalGraph **out);
 hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream);
 void eval_graph_destroy(EvalGraph *g);
+// n_iters optimisation steps -- energy + gradient, then the AdamUniform update of x from that gradient -- as ONE graph: per
+// step a tile node, a finish node and the two optimiser nodes, chained; x is updated in place and read by the next step.
+// e.x = the parameter, e.grad = its gradient buffer, e.energy = a ring of n_iters floats (step k writes slot k); ws = 2 * n_iters
+// dwords.  A launch takes the per-step coefficients, orders and optimiser scalars as kernel-node arguments.
+struct TrainLoopGraph;
+struct TrainLoopStep {
+    float c1, c2;
+    int order;
+    float bias1, bias2, limit;   // AdamUniform: 1 - beta^step, and the step limit (< 0: none)
+};
+hipError_t train_loop_create(const EvalArgs &e, float *param, float *g1, float *g2, int64_t n_param, void *ws, int n_iters, TrainLoopGraph **out);
+hipError_t train_loop_launch(TrainLoopGraph *g, const TrainLoopStep *steps, float lr, float b1, float b2, hipStream_t stream);
+void train_loop_destroy(TrainLoopGraph *g);
 hipError_t launch_finish(const int32_t *fin_vid, const int32_t *fin_off, int64_t n_finish, const float *stage, float *grad,
                          const float *grad_out, const double *partials, int64_t n_partials, float c1, float c2, float *energy,
                          double *terms, hipStream_t stream);

@@ -22,6 +22,8 @@
 // per forward+backward: :154, :185, :257).
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "kernels.h"
 
 namespace tsamd {
@@ -1260,6 +1262,146 @@ hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t strea
 }
 
 void eval_graph_destroy(EvalGraph *g)
+{
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
+// ---- n optimisation steps as one graph (trainer.py:128-133 folded: energy + backward, optimizer.step) ----
+// Every step is four kernel nodes in a chain -- tile, finish, adam_moments, adam_apply -- and the steps are chained to each
+// other through the parameter (apply of step k writes what tile of step k + 1 reads).  Nothing per step on the host: one launch
+// per n steps, the schedule (coefficients, order, bias corrections, step limit) goes in as node arguments beforehand.
+struct TrainLoopGraph {
+    struct Adam {
+        const float *grad;
+        float *g1, *g2, *p;
+        int64_t n;
+        float b1, b2, lr, bias1, bias2, limit;
+        unsigned int *ws;
+    };
+    int n = 0;
+    std::vector<LaunchRecipe> r;
+    std::vector<Adam> adam;
+    std::vector<hipGraphNode_t> tile, finish, moments, apply;
+    std::vector<hipKernelNodeParams> tile_p, finish_p, moments_p, apply_p;
+    std::vector<void *> argv;     // [n][1 + 1 + 7 + 8]
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int adam_grid = 0;
+};
+
+hipError_t train_loop_create(const EvalArgs &e, float *param, float *g1, float *g2, int64_t n_param, void *ws, int n_iters, TrainLoopGraph **out)
+{
+    *out = nullptr;
+    if (n_iters < 1 || n_iters > 4096 || n_param < 1 || !e.grad || !e.energy) return hipErrorInvalidValue;
+    TrainLoopGraph *g = new TrainLoopGraph();
+    auto fail = [&](hipError_t code) {
+        train_loop_destroy(g);
+        return code;
+    };
+    g->n = n_iters;
+    g->r.resize(n_iters);
+    g->adam.resize(n_iters);
+    g->tile.assign(n_iters, nullptr);
+    g->finish.assign(n_iters, nullptr);
+    g->moments.assign(n_iters, nullptr);
+    g->apply.assign(n_iters, nullptr);
+    g->tile_p.resize(n_iters);
+    g->finish_p.resize(n_iters);
+    g->moments_p.resize(n_iters);
+    g->apply_p.resize(n_iters);
+    g->argv.resize(size_t(n_iters) * 17);
+    g->adam_grid = grid_for(n_param, 1024, 4096);
+    hipError_t err;
+    if ((err = hipGraphCreate(&g->graph, 0)) != hipSuccess) return fail(err);
+    // the optimiser's two-dword scratch of every step, zeroed once per launch
+    hipGraphNode_t prev = nullptr;
+    {
+        hipMemsetParams m = {};
+        m.dst = ws;
+        m.elementSize = 4;
+        m.width = size_t(2 * n_iters);
+        m.height = 1;
+        m.value = 0;
+        if ((err = hipGraphAddMemsetNode(&prev, g->graph, nullptr, 0, &m)) != hipSuccess) return fail(err);
+    }
+    for (int k = 0; k < n_iters; ++k) {
+        EvalArgs ek = e;
+        ek.x = param;
+        ek.energy = e.energy + k;
+        if ((err = make_recipe(ek, g->r[k])) != hipSuccess) return fail(err);
+        LaunchRecipe &r = g->r[k];
+        void **av = g->argv.data() + size_t(k) * 17;
+        auto add = [&](hipGraphNode_t *node, hipKernelNodeParams &p, const void *fn, dim3 grid, dim3 block, size_t lds, void **args) {
+            p = hipKernelNodeParams{};
+            p.func = const_cast<void *>(fn);
+            p.gridDim = grid;
+            p.blockDim = block;
+            p.sharedMemBytes = unsigned(lds);
+            p.kernelParams = args;
+            p.extra = nullptr;
+            const hipError_t rc = hipGraphAddKernelNode(node, g->graph, prev ? &prev : nullptr, prev ? 1 : 0, &p);
+            if (rc == hipSuccess) prev = *node;
+            return rc;
+        };
+        if (r.tile_fn) {
+            av[0] = &r.k;
+            if ((err = add(&g->tile[k], g->tile_p[k], r.tile_fn, r.tile_grid, r.tile_block, r.tile_lds, av)) != hipSuccess) return fail(err);
+        }
+        if (r.finish_fn) {
+            av[1] = &r.f;
+            if ((err = add(&g->finish[k], g->finish_p[k], r.finish_fn, r.finish_grid, r.finish_block, 0, av + 1)) != hipSuccess) return fail(err);
+        }
+        TrainLoopGraph::Adam &a = g->adam[k];
+        a = TrainLoopGraph::Adam{e.grad, g1, g2, param, n_param, 0.9f, 0.999f, 0.f, 1.f, 1.f, -1.f, static_cast<unsigned int *>(ws) + 2 * k};
+        void **am = av + 2, **aa = av + 9;
+        am[0] = &a.grad, am[1] = &a.g1, am[2] = &a.g2, am[3] = &a.n, am[4] = &a.b1, am[5] = &a.b2, am[6] = &a.ws;
+        aa[0] = &a.p, aa[1] = &a.g1, aa[2] = &a.n, aa[3] = &a.lr, aa[4] = &a.bias1, aa[5] = &a.bias2, aa[6] = &a.limit, aa[7] = &a.ws;
+        if ((err = add(&g->moments[k], g->moments_p[k], reinterpret_cast<const void *>(&adam_moments_kernel), dim3(unsigned(g->adam_grid)), dim3(256), 0,
+                       am)) != hipSuccess)
+            return fail(err);
+        if ((err = add(&g->apply[k], g->apply_p[k], reinterpret_cast<const void *>(&adam_apply_kernel), dim3(unsigned(g->adam_grid)), dim3(256), 0, aa)) !=
+            hipSuccess)
+            return fail(err);
+    }
+    if ((err = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0)) != hipSuccess) return fail(err);
+    *out = g;
+    return hipSuccess;
+}
+
+hipError_t train_loop_launch(TrainLoopGraph *g, const TrainLoopStep *steps, float lr, float b1, float b2, hipStream_t stream)
+{
+    hipError_t err;
+    for (int k = 0; k < g->n; ++k) {
+        LaunchRecipe &r = g->r[k];
+        const TrainLoopStep &s = steps[k];
+        if (r.k.c1 != s.c1 || r.k.c2 != s.c2 || r.k.order != s.order || r.f.c1 != s.c1 || r.f.c2 != s.c2) {
+            r.k.c1 = r.f.c1 = s.c1;
+            r.k.c2 = r.f.c2 = s.c2;
+            r.k.order = s.order;
+            if (g->tile[k] && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile[k], &g->tile_p[k])) != hipSuccess) return err;
+            if (g->finish[k] && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish[k], &g->finish_p[k])) != hipSuccess) return err;
+        }
+        TrainLoopGraph::Adam &a = g->adam[k];
+        if (a.b1 != b1 || a.b2 != b2) {
+            a.b1 = b1;
+            a.b2 = b2;
+            if ((err = hipGraphExecKernelNodeSetParams(g->exec, g->moments[k], &g->moments_p[k])) != hipSuccess) return err;
+        }
+        if (a.lr != lr || a.bias1 != s.bias1 || a.bias2 != s.bias2 || a.limit != s.limit) {
+            a.lr = lr;
+            a.bias1 = s.bias1;
+            a.bias2 = s.bias2;
+            a.limit = s.limit;
+            if ((err = hipGraphExecKernelNodeSetParams(g->exec, g->apply[k], &g->apply_p[k])) != hipSuccess) return err;
+        }
+    }
+    return hipGraphLaunch(g->exec, stream);
+}
+
+void train_loop_destroy(TrainLoopGraph *g)
 {
     if (!g) return;
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
