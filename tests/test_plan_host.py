@@ -144,6 +144,16 @@ def test_error_behaviour(ext, capsys):
     assert lib.tsamd_create(v32.ctypes.data, v32.shape[0], t.ctypes.data, t.shape[0], C.byref(o), C.byref(h)) == 1
 
 
+def test_train_loop_abi_checks_arguments():
+    lib = _capi.load()
+    assert lib.tsamd_train_loop_workspace_bytes(0) == -1 and lib.tsamd_train_loop_workspace_bytes(32) == 256
+    out = C.c_void_p()
+    assert lib.tsamd_train_loop_create(None, None, None, None, None, None, None, 4, C.byref(out)) == 1 and not out
+    assert lib.tsamd_train_loop_launch(None, None, None, None, 0.1, 0.9, 0.999, 1, None, None) == 1
+    assert b"null" in lib.tsamd_last_error()
+    lib.tsamd_train_loop_destroy(None)                            # a no-op, like free(NULL)
+
+
 def test_library_exports_every_declared_symbol():
     """include/tssplat_amd.h is the contract: every function it declares must be exported."""
     import os
