@@ -181,7 +181,14 @@ __device__ __forceinline__ void pixel_blends(const float4 *rast_view, const floa
     }
 }
 
-__global__ __launch_bounds__(256) void antialias_kernel(const float *color, const float4 *rast, const float4 *pos, const int32_t *tri, const int32_t *opp,
+// Occupancy: the float64 analysis wants 100 (forward) / 130 (backward) VGPRs, but ~99 % of the lanes only compare two triangle
+// ids and their speed is the occupancy the register count leaves (3-5 waves per SIMD).  Both kernels are therefore held to
+// 64 VGPRs = 8 waves per SIMD and the analysis spills (2 / 92 dwords of scratch, touched by silhouette lanes only).  Measured,
+// forward / forward + backward: 120 views x 512^2 of one object 0.33 / 0.78 -> 0.53 ms for both; 8 dense views 0.087 / 0.23 ->
+// 0.067 / 0.26 ms.  (Detect-then-analyse with pair lists was built and measured: a global list serialises on its append counter,
+// 0.42 ms for the 8 dense views; per-256-pixel lists without atomics 0.16 / 0.40 and 0.62 ms -- an extra pass over `rast` and
+// a second read of every pair cost more than the spills.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_kernel(const float *color, const float4 *rast, const float4 *pos, const int32_t *tri, const int32_t *opp,
                                                         int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, int channels, float *out)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(256) void antialias_kernel(const float *color, cons
     });
 }
 
-__global__ __launch_bounds__(256) void antialias_backward_kernel(const float *color, const float4 *rast, const float4 *pos, const int32_t *tri,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_backward_kernel(const float *color, const float4 *rast, const float4 *pos, const int32_t *tri,
                                                                  const int32_t *opp, int64_t batch, int64_t n_vertices, int64_t n_tri, int height,
                                                                  int width, int channels, const float *grad_out, float boost, float *grad_color,
                                                                  float4 *grad_pos)
