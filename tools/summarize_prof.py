@@ -43,7 +43,8 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
 
     if args.stats:
-        src = glob.glob(os.path.join(args.stats, "*", "*kernel_stats.csv"))
+        # (gpurun MERGES a call's output into gpurun_out/: an earlier round-trip may have left an older file next to the new one)
+        src = sorted(glob.glob(os.path.join(args.stats, "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
         if src:
             shutil.copy(src[0], os.path.join(out_dir, f"{args.round}_kernel_stats.csv"))
             print("wrote", f"profiles/{args.round}_kernel_stats.csv")
@@ -51,7 +52,7 @@ def main():
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     meta = {}
     for d in args.pmc:
-        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+        for f in sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)[:1]:
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
