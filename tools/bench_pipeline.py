@@ -24,7 +24,6 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     import torch
-    from oracle import raster_oracle as R          # cameras only
     from tssplat_amd import geometry, renderers, scenes
     from tssplat_amd.utils.optimizer import AdamUniform
 
@@ -32,7 +31,7 @@ def main():
     sc = scenes.make_scene(args.scene, args.spheres)
     geo = geometry.TetMeshGeometry(sc.rest, sc.tets, smooth_barrier_param=flags)
     ren = renderers.MeshRasterizer(geo)
-    mvp = torch.from_numpy(R.orbit_mvps(args.views)).cuda()
+    mvp = torch.from_numpy(scenes.orbit_mvps(args.views)).cuda()
     opt = AdamUniform(ren.parameters(), lr=0.2, grad_limit=True, grad_limit_values=[0.01, 0.01], grad_limit_iters=[1500])
     with torch.no_grad():
         target = (ren(mvp, only_alpha=True, iter_num=0, resolution=args.res)["shaded"] * 0.9).clone()

@@ -28,15 +28,14 @@ def main():
     args = ap.parse_args()
     import numpy as np
     import torch
-    from oracle import raster_oracle as R          # cameras only (orbit_mvps / transform_pos): set-up, not the thing measured
     from tssplat_amd import geometry, scenes
     import tssplat_amd.dr as dr
 
     sc = scenes.make_scene(args.scene, args.spheres)
     vid, faces = geometry.get_surface_vf(sc.tets)
     v = scenes.deform(sc, 0.02)[np.asarray(vid)]
-    mvp = R.orbit_mvps(args.views)
-    pos = torch.from_numpy(R.transform_pos(mvp, v)).cuda()
+    mvp = scenes.orbit_mvps(args.views)
+    pos = torch.from_numpy(scenes.transform_pos(mvp, v)).cuda()
     tri = torch.from_numpy(np.asarray(faces, dtype=np.int32)).cuda()
     attr = torch.from_numpy(v[None].astype(np.float32)).cuda().requires_grad_(True)
     ctx = dr.RasterizeCudaContext()

@@ -21,11 +21,24 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import c_oracle                                   # face adjacency only (offline study, not product)
 from tssplat_amd import scenes, tet_spheres_ext as T
 
 RECORD = 48
 LIVE_LEVELS = 6
+
+
+def face_adjacency(tets):
+    """nbr[e, k] = the tet across the face opposite local vertex k, or -1 (sort of the 4 m sorted vertex triples)."""
+    m = tets.shape[0]
+    faces = np.stack([np.sort(np.delete(tets, k, axis=1), axis=1) for k in range(4)], axis=1).reshape(-1, 3).astype(np.int64)
+    key = (faces[:, 0] << 42) | (faces[:, 1] << 21) | faces[:, 2]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    same = ks[1:] == ks[:-1]
+    nbr = np.full(4 * m, -1, dtype=np.int64)
+    a, b = order[:-1][same], order[1:][same]
+    nbr[a], nbr[b] = b // 4, a // 4
+    return nbr.reshape(m, 4)
 
 
 def tubes(cen, k, axes):
@@ -41,7 +54,7 @@ def tubes(cen, k, axes):
 
 def study(name, rest, tets):
     m = tets.shape[0]
-    nbr = c_oracle.face_adjacency(tets)
+    nbr = face_adjacency(tets)
     cen = rest[tets].mean(axis=1)
     ext = cen.max(axis=0) - cen.min(axis=0)
     sweep = int(np.argmax(ext))

@@ -292,3 +292,33 @@ def write_veg(path: str | os.PathLike, verts: np.ndarray, tets: np.ndarray) -> N
         fh.write(f"{tets.shape[0]} 4 0\n")
         for i, t in enumerate(np.asarray(tets, dtype=np.int64)):
             fh.write(f"{i + 1} {t[0] + 1} {t[1] + 1} {t[2] + 1} {t[3] + 1}\n")
+
+
+# ---- cameras for the renderer benches (tools/bench_raster.py, tools/bench_pipeline.py) ----
+def orbit_mvps(n_views: int, distance: float = 3.0, fov_deg: float = 40.0, near: float = 0.5, far: float = 8.0,
+               elevation_deg: float = 20.0) -> np.ndarray:
+    """``n_views`` model-view-projection matrices (float32 ``[n, 4, 4]``, OpenGL clip space) on a circle around the origin --
+    the kind of batch /root/reference/data/*.py hands to ``MeshRasterizer.forward(mvp, ...)``.  (The renderer oracle keeps its
+    own copy: product code never imports ``oracle/``.)"""
+    f = 1.0 / np.tan(np.radians(fov_deg) / 2.0)
+    proj = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, (far + near) / (near - far), 2 * far * near / (near - far)], [0, 0, -1, 0]])
+    el = np.radians(elevation_deg)
+    out = []
+    for k in range(n_views):
+        az = 2 * np.pi * k / n_views
+        eye = distance * np.array([np.cos(el) * np.sin(az), np.sin(el), np.cos(el) * np.cos(az)])
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(fwd, [0.0, 1.0, 0.0])
+        right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        view = np.eye(4)
+        view[0, :3], view[1, :3], view[2, :3] = right, up, -fwd
+        view[:3, 3] = -view[:3, :3] @ eye
+        out.append(proj @ view)
+    return np.stack(out).astype(np.float32)
+
+
+def transform_pos(mvp: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """``[v, 1] @ mvp^T`` per view, float32 (mesh_rasterizer.py:57-78, non-ortho branch)."""
+    posw = np.concatenate([np.asarray(pos, dtype=np.float32), np.ones((pos.shape[0], 1), dtype=np.float32)], axis=1)
+    return np.matmul(posw[None], np.transpose(np.asarray(mvp, dtype=np.float32), (0, 2, 1))).astype(np.float32)
