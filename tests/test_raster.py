@@ -305,6 +305,36 @@ def test_rasterize_edge_cases_on_gpu():
 
 
 @pytest.mark.gpu
+def test_rasterize_large_triangles_take_the_64_bit_walk():
+    """Triangles wider than 64 pixels leave the 32-bit edge functions (|E| < 2^30) for the 64-bit walk; mixed with small ones in
+    the same wave, partly off-screen, interpenetrating: ids bit-exact against the oracle."""
+    import torch
+    import tssplat_amd.dr as dr
+    ctx = dr.RasterizeCudaContext()
+    rng = np.random.default_rng(12)
+    H, W = 200, 300
+    n = 60
+    pts = rng.uniform(-1.6, 1.6, (n, 2))
+    w = rng.uniform(0.7, 2.0, n)
+    pos = np.concatenate([pts * w[:, None], (rng.uniform(-0.8, 0.8, n) * w)[:, None], w[:, None]], axis=1).astype(np.float32)
+    big = rng.integers(0, n, (24, 3))
+    small_c = rng.uniform(-0.9, 0.9, (40, 2))
+    small = np.concatenate([small_c + rng.uniform(-0.05, 0.05, (40, 2)) for _ in range(3)], axis=0).reshape(3, 40, 2).transpose(1, 0, 2).reshape(-1, 2)
+    spos = np.concatenate([small, rng.uniform(-0.5, 0.5, (120, 1)), np.ones((120, 1))], axis=1).astype(np.float32)
+    pos = np.concatenate([pos, spos])
+    tri = np.concatenate([big, n + np.arange(120).reshape(40, 3)]).astype(np.int32)
+    pos[:4] = [[-3, -3, 0.5, 1], [3, -3, 0.5, 1], [3, 3, 0.5, 1], [-3, 3, 0.5, 1]]           # a screen-filling pair behind everything
+    tri = np.concatenate([tri, [[0, 1, 2], [0, 2, 3]]]).astype(np.int32)
+    ref = R.rasterize(pos[None], tri, (H, W))
+    rast, _ = dr.rasterize(ctx, torch.from_numpy(pos[None]).cuda(), torch.from_numpy(tri).cuda(), resolution=[H, W], grad_db=False)
+    got = rast.cpu().numpy().astype(np.float64)
+    assert (ref[..., 3] > 0).all()                                               # the backdrop covers the screen
+    assert len(np.unique(ref[..., 3])) > 30                                      # and many triangles of both kinds are visible
+    assert np.array_equal(got[..., 3], ref[..., 3])
+    assert np.abs(got[..., :3] - ref[..., :3]).max() <= 5e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("attr_batch_is_one", [True, False])
 def test_interpolate_forward_backward(attr_batch_is_one):
     import torch
