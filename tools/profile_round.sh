@@ -35,6 +35,7 @@ python tools/bench_raster.py --spheres 64 > $OUT/bench_raster64.json 2>> $OUT/be
 python tools/bench_pipeline.py > $OUT/pipeline_512.json 2> $OUT/pipeline.log
 python tools/bench_pipeline.py --spheres 1 > $OUT/pipeline_1.json 2>> $OUT/pipeline.log
 python tools/bench_pipeline.py --spheres 1 --views 120 --iters 10 > $OUT/pipeline_1x120.json 2>> $OUT/pipeline.log
+python tools/train_synthetic.py > $OUT/train_synthetic.json 2>> $OUT/pipeline.log
 for cfg in "kuhn8 64" "kuhn8 256"; do set -- $cfg
   python tools/bench_train_loop.py --scene $1 --spheres $2 > $OUT/train_loop_$1x$2.json 2>> $OUT/pipeline.log
 done
