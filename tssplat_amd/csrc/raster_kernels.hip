@@ -276,6 +276,42 @@ __global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *po
     rast[gid] = make_float4(fminf(fmaxf(b0, 0.f), 1.f), fminf(fmaxf(b1, 0.f), 1.f), fminf(fmaxf(z / w, -1.f), 1.f), float(t + 1));
 }
 
+// ---- scatter with runs ----
+// The backward scatters add one value per pixel to the three vertices of the pixel's triangle.  Consecutive pixels of a row
+// mostly belong to the same triangle (a 41 k-tet object at 512^2: runs of ~5), so the lanes of a run are summed inside the wave
+// first -- a segmented scan over equal keys -- and only the last lane of every run issues the atomics.  A wave without any run
+// (a dense scene of sub-pixel triangles) skips the scan.  EVERY lane of the wave must call these (no early return before).
+struct Runs {
+    int start;      // lane index of the first lane of this lane's run
+    bool last;      // this lane ends its run: it holds the run's sums after run_sum()
+    bool any;       // wave-uniform: some run is longer than one lane
+};
+
+__device__ __forceinline__ Runs find_runs(long long key)
+{
+    const int lane = int(threadIdx.x) & 63;
+    const long long prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(head);
+    Runs r;
+    r.start = 63 - __clzll(heads & (~0ull >> (63 - lane)));
+    r.last = lane == 63 || ((heads >> (lane + 1)) & 1ull) != 0ull;
+    r.any = heads != ~0ull;
+    return r;
+}
+
+__device__ __forceinline__ float run_sum(const Runs &r, float v)
+{
+    if (!r.any) return v;
+    const int lane = int(threadIdx.x) & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float up = __shfl_up(v, d);
+        if (lane - d >= r.start) v += up;
+    }
+    return v;
+}
+
 // d (u, v) / d clip-space positions of the winning triangle (oracle/raster_oracle.py::rasterize_backward): the barycentrics
 // are ratios of the homogeneous edge functions of `resolve`, so this is their quotient rule; z/w and the id carry no gradient
 // (as in nvdiffrast), the clamps of the forward are treated as inactive.  fp32 atomics into grad_pos.
@@ -284,41 +320,60 @@ __global__ __launch_bounds__(256) void rasterize_backward_kernel(const float4 *p
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t hw = int64_t(height) * width;
-    if (gid >= batch * hw) return;
-    const int64_t t = int64_t(rast[gid].w) - 1;
-    if (t < 0 || t >= n_tri) return;
-    const float4 g = grad_rast[gid];
-    if (g.x == 0.f && g.y == 0.f) return;
-    const int64_t b = gid / hw, pix = gid - b * hw;
-    const int py = int(pix / width), px = int(pix - int64_t(py) * width);
-    const int32_t i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    if (i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices) return;
-    const float4 *pv = pos + b * n_vertices;
-    const float4 v0 = pv[i0], v1 = pv[i1], v2 = pv[i2];
-    const float fx = (float(px) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py) + 0.5f) / float(height) * 2.f - 1.f;
-    const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
-    const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
-    const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
-    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-    float s = a0 + a1 + a2;
-    s = s == 0.f ? 1.f : s;
-    const float is = 1.f / s;
-    const float u = a0 * is, v = a1 * is;
-    const float dot = g.x * u + g.y * v;
-    const float da0 = (g.x - dot) * is, da1 = (g.y - dot) * is, da2 = -dot * is;
-    const float d0x = da1 * -p2y + da2 * p1y, d0y = da1 * p2x + da2 * -p1x;
-    const float d1x = da0 * p2y + da2 * -p0y, d1y = da0 * -p2x + da2 * p0x;
-    const float d2x = da0 * -p1y + da1 * p0y, d2y = da0 * p1x + da1 * -p0x;
-    float *gp = reinterpret_cast<float *>(grad_pos + b * n_vertices);
-    atomicAdd(gp + 4 * int64_t(i0) + 0, d0x);
-    atomicAdd(gp + 4 * int64_t(i0) + 1, d0y);
-    atomicAdd(gp + 4 * int64_t(i0) + 3, -fx * d0x - fy * d0y);
-    atomicAdd(gp + 4 * int64_t(i1) + 0, d1x);
-    atomicAdd(gp + 4 * int64_t(i1) + 1, d1y);
-    atomicAdd(gp + 4 * int64_t(i1) + 3, -fx * d1x - fy * d1y);
-    atomicAdd(gp + 4 * int64_t(i2) + 0, d2x);
-    atomicAdd(gp + 4 * int64_t(i2) + 1, d2y);
-    atomicAdd(gp + 4 * int64_t(i2) + 3, -fx * d2x - fy * d2y);
+    bool valid = gid < batch * hw;
+    int64_t t = -1;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+        t = int64_t(rast[gid].w) - 1;
+        valid = t >= 0 && t < n_tri;
+    }
+    if (valid) {
+        g = grad_rast[gid];
+        valid = !(g.x == 0.f && g.y == 0.f);
+    }
+    const int64_t b = valid ? gid / hw : 0, pix = valid ? gid - b * hw : 0;
+    int32_t i0 = 0, i1 = 0, i2 = 0;
+    if (valid) {
+        i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        valid = !(i0 < 0 || i1 < 0 || i2 < 0 || i0 >= n_vertices || i1 >= n_vertices || i2 >= n_vertices);
+    }
+    float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // (x, y, w) of the three vertices
+    if (valid) {
+        const int py = int(pix / width), px = int(pix - int64_t(py) * width);
+        const float4 *pv = pos + b * n_vertices;
+        const float4 v0 = pv[i0], v1 = pv[i1], v2 = pv[i2];
+        const float fx = (float(px) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py) + 0.5f) / float(height) * 2.f - 1.f;
+        const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
+        const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
+        const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
+        const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+        float s = a0 + a1 + a2;
+        s = s == 0.f ? 1.f : s;
+        const float is = 1.f / s;
+        const float u = a0 * is, v = a1 * is;
+        const float dot = g.x * u + g.y * v;
+        const float da0 = (g.x - dot) * is, da1 = (g.y - dot) * is, da2 = -dot * is;
+        d[0] = da1 * -p2y + da2 * p1y, d[1] = da1 * p2x + da2 * -p1x;
+        d[3] = da0 * p2y + da2 * -p0y, d[4] = da0 * -p2x + da2 * p0x;
+        d[6] = da0 * -p1y + da1 * p0y, d[7] = da0 * p1x + da1 * -p0x;
+        d[2] = -fx * d[0] - fy * d[1];
+        d[5] = -fx * d[3] - fy * d[4];
+        d[8] = -fx * d[6] - fy * d[7];
+    }
+    // lanes of one triangle (and view) in a row: one set of atomics per run
+    const Runs runs = find_runs(valid ? b * (int64_t(1) << 32) + t : -1 - int64_t(threadIdx.x));
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = run_sum(runs, d[k]);
+    if (valid && runs.last) {
+        float *gp = reinterpret_cast<float *>(grad_pos + b * n_vertices);
+        const int64_t at[3] = {4 * int64_t(i0), 4 * int64_t(i1), 4 * int64_t(i2)};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicAdd(gp + at[k] + 0, d[3 * k]);
+            atomicAdd(gp + at[k] + 1, d[3 * k + 1]);
+            atomicAdd(gp + at[k] + 3, d[3 * k + 2]);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
@@ -340,36 +395,43 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int
     for (int c = 0; c < channels; ++c) o[c] = u * a0[c] + v * a1[c] + w * a2[c];
 }
 
-// d out / d attr: scatter of the three barycentric weights (fp32 global atomics: the order of the additions, and so the
-// last bits of the result, vary from run to run -- like nvdiffrast's own backward); d out / d (u, v) per pixel.
+// d out / d attr: scatter of the three barycentric weights, summed over runs of equal triangles inside the wave first (fp32
+// global atomics: the order of the additions, and so the last bits of the result, vary from run to run -- like nvdiffrast's
+// own backward); d out / d (u, v) per pixel.
 __global__ __launch_bounds__(256) void interpolate_backward_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
                                                                    const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw,
                                                                    const float *grad_out, float *grad_attr, float4 *grad_rast)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= batch * hw) return;
-    const float4 r = rast[gid];
+    const bool inside = gid < batch * hw;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (inside) r = rast[gid];
     const int64_t t = int64_t(r.w) - 1;
-    if (t < 0) {
-        if (grad_rast) grad_rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    const int64_t b = gid / hw;
+    const bool valid = inside && t >= 0;
+    if (inside && !valid && grad_rast) grad_rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t b = valid ? gid / hw : 0;
     const int64_t base = (attr_batch > 1 ? b : 0) * n_vertices * channels;
-    const int64_t o0 = base + int64_t(tri[3 * t]) * channels, o1 = base + int64_t(tri[3 * t + 1]) * channels, o2 = base + int64_t(tri[3 * t + 2]) * channels;
+    int64_t o0 = 0, o1 = 0, o2 = 0;
+    if (valid) o0 = base + int64_t(tri[3 * t]) * channels, o1 = base + int64_t(tri[3 * t + 1]) * channels, o2 = base + int64_t(tri[3 * t + 2]) * channels;
     const float u = r.x, v = r.y, w = 1.f - r.x - r.y;
-    const float *g = grad_out + gid * channels;
+    // lanes of one triangle (and attribute batch) in a row: one set of atomics per run
+    const Runs runs = find_runs(valid ? (attr_batch > 1 ? b : 0) * (int64_t(1) << 32) + t : -1 - int64_t(threadIdx.x));
     float du = 0.f, dv = 0.f;
     for (int c = 0; c < channels; ++c) {
-        const float gc = g[c];
-        atomicAdd(grad_attr + o0 + c, u * gc);
-        atomicAdd(grad_attr + o1 + c, v * gc);
-        atomicAdd(grad_attr + o2 + c, w * gc);
-        const float a2 = attr[o2 + c];
-        du += gc * (attr[o0 + c] - a2);
-        dv += gc * (attr[o1 + c] - a2);
+        const float gc = valid ? grad_out[gid * channels + c] : 0.f;
+        const float s0 = run_sum(runs, u * gc), s1 = run_sum(runs, v * gc), s2 = run_sum(runs, w * gc);
+        if (valid) {
+            if (runs.last) {
+                atomicAdd(grad_attr + o0 + c, s0);
+                atomicAdd(grad_attr + o1 + c, s1);
+                atomicAdd(grad_attr + o2 + c, s2);
+            }
+            const float a2 = attr[o2 + c];
+            du += gc * (attr[o0 + c] - a2);
+            dv += gc * (attr[o1 + c] - a2);
+        }
     }
-    if (grad_rast) grad_rast[gid] = make_float4(du, dv, 0.f, 0.f);
+    if (valid && grad_rast) grad_rast[gid] = make_float4(du, dv, 0.f, 0.f);
 }
 
 unsigned blocks_for(int64_t n) { return unsigned((n + 255) / 256); }
