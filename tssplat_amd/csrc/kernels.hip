@@ -186,12 +186,20 @@ __device__ __forceinline__ Mat9 mat9_of(const float *m)
     return r;
 }
 
-__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 acc, const uint32_t *nb)
+__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 acc, const uint32_t *nb
+#ifdef TSAMD_EXP_PARTNER   // experiment (wrong results): neighbour 0 taken from registers -- what a lane-local face partner would save
+                                               , const Mat9 &partner
+#endif
+)
 {
 #ifdef TSAMD_PRIO   // experiment: waves that are issuing gathers win the arbitration against waves doing algebra
     __builtin_amdgcn_s_setprio(TSAMD_PRIO);
 #endif
+#ifdef TSAMD_EXP_PARTNER
+    Mat9 g0 = partner;
+#else
     Mat9 g0 = load_slot(lds, nb[0]);
+#endif
     acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
     acc.p8 *= 4.f;
     Mat9 g1 = load_slot(lds, nb[1]);
@@ -493,7 +501,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
                     h = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
+#ifdef TSAMD_EXP_PARTNER
+                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own[p]), nb, mat9_of(Fk[1 - p]));
+#else
                     h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own[p]), nb);
+#endif
                 }
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
@@ -601,7 +613,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
                     q = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
                 } else {
+#ifdef TSAMD_EXP_PARTNER
+                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb, mat9_of(H[1 - p]));
+#else
                     q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb);
+#endif
                 }
 #ifdef TSAMD_DUMMY_VALU  // experiments: marginal cost of VALU instructions (independent FMAs on four accumulators)
                 {
