@@ -414,7 +414,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     if launch_mode == "auto":                          # a few steps of each, after a pre-heat; ranks agree on rank 0's choice
         for name, fn in (("graph", step_graph), ("eager", step_eager)):
             preheat()
-            probe[name] = timed(fn, 10, 3)[0] / 10
+            probe[name] = timed(fn, 30, 5)[0] / 30
             if reducer is not None:
                 reducer.results()
         # (replay only where it clearly wins: on the 21 M-tet scene the two are within the probe's noise)
