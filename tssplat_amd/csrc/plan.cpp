@@ -343,8 +343,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             return ERR_INVALID;
         }
     timer.lap("index check");
-    int nthreads = opt.num_threads > 0 ? opt.num_threads : int(std::thread::hardware_concurrency());
-    nthreads = std::max(1, std::min(nthreads, 64));
+    // Default: all cores up to 32.  More did not help where it was measured (256-core EPYC 9575F host of the MI355X box, 21 M
+    // tets): 32 threads 2.8 s, 64 threads 3.4 s, 128 asked (= 64) 3.4 s -- the bisection and pass A get slower, pass B (planes,
+    // colouring, incidence matching: 1.0-1.1 s) does not get faster.  An explicit num_threads is honoured up to 64.
+    int nthreads = opt.num_threads > 0 ? std::min(opt.num_threads, 64) : std::min(int(std::thread::hardware_concurrency()), 32);
+    nthreads = std::max(1, nthreads);
     constexpr int spt = kSlotsPerLane;
     // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU -- with or without an explicit operator (its nine
     // extra planes live in registers, not in LDS, and the kernel still fits 80 VGPRs).
