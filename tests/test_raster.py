@@ -432,3 +432,26 @@ def test_rasterize_backward_through_interpolate():
     scale = np.abs(gp).max()
     assert np.abs(got - gp).max() <= 2e-3 * scale
     assert np.abs(got - gp).mean() <= 2e-5 * scale
+
+
+@pytest.mark.gpu
+def test_renderer_operators_on_empty_inputs():
+    """No triangles / nothing on screen: rasterize gives the background, interpolate zeros, antialias the identity (and its
+    backward hands the upstream gradient straight to the colour); an off-screen mesh leaves no gradient on the positions."""
+    import torch
+    import tssplat_amd.dr as dr
+    ctx = dr.RasterizeCudaContext()
+    pos = torch.tensor([[[5.0, 5.0, 0.0, 1.0], [6.0, 5.0, 0.0, 1.0], [5.0, 6.0, 0.0, 1.0]]], device="cuda", requires_grad=True)   # off screen
+    for tri in (torch.zeros((0, 3), dtype=torch.int32, device="cuda"), torch.tensor([[0, 1, 2]], dtype=torch.int32, device="cuda")):
+        rast, _ = dr.rasterize(ctx, pos, tri, resolution=[16, 24], grad_db=False)
+        assert rast.shape == (1, 16, 24, 4) and float(rast.detach().abs().max()) == 0.0
+        out, _ = dr.interpolate(pos.detach()[..., :3].contiguous(), rast, tri)
+        assert float(out.detach().abs().max()) == 0.0
+        col = torch.rand(1, 16, 24, 3, device="cuda", requires_grad=True)
+        aa = dr.antialias(col, rast, pos, tri)
+        assert torch.equal(aa, col)
+        g = torch.randn_like(col)
+        pos.grad = None
+        aa.backward(g)
+        assert torch.equal(col.grad, g)
+        assert pos.grad is None or float(pos.grad.abs().max()) == 0.0

@@ -52,6 +52,20 @@ def _check_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
+_dummy_tri: dict = {}
+
+
+def _tri_ptr(tri: torch.Tensor) -> int:
+    """Device address of the index list; an EMPTY list has none (torch hands out 0), and tsamd_interpolate -- which is not told
+    the triangle count -- rejects a null pointer: a three-entry dummy stands in (no pixel of `rast` can refer to it)."""
+    if tri.numel() > 0:
+        return tri.data_ptr()
+    d = _dummy_tri.get(tri.device)
+    if d is None:
+        d = _dummy_tri[tri.device] = torch.zeros(3, dtype=torch.int32, device=tri.device)
+    return d.data_ptr()
+
+
 def _check_tri(tri: torch.Tensor, device) -> torch.Tensor:
     if not isinstance(tri, torch.Tensor) or tri.dim() != 2 or tri.shape[1] != 3:
         raise RuntimeError("tssplat_amd.dr: tri must be an [T, 3] tensor")
@@ -111,7 +125,7 @@ class _InterpolateFunc(torch.autograd.Function):
         A, V, Cn = int(attr.shape[0]), int(attr.shape[1]), int(attr.shape[2])
         out = torch.empty((B, H, W, Cn), dtype=torch.float32, device=rast.device)
         with _device_ctx(rast.device):
-            _capi.check(_lib.tsamd_interpolate(attr.data_ptr(), A, V, Cn, rast.data_ptr(), tri.data_ptr(), B, H, W, out.data_ptr(),
+            _capi.check(_lib.tsamd_interpolate(attr.data_ptr(), A, V, Cn, rast.data_ptr(), _tri_ptr(tri), B, H, W, out.data_ptr(),
                                                _stream_ptr(rast.device)))
         ctx.save_for_backward(attr, rast, tri)
         return out
@@ -125,7 +139,7 @@ class _InterpolateFunc(torch.autograd.Function):
         grad_attr = torch.empty_like(attr)
         grad_rast = torch.empty_like(rast) if ctx.needs_input_grad[1] else None
         with _device_ctx(rast.device):
-            _capi.check(_lib.tsamd_interpolate_backward(attr.data_ptr(), A, V, Cn, rast.data_ptr(), tri.data_ptr(), B, H, W, g.data_ptr(),
+            _capi.check(_lib.tsamd_interpolate_backward(attr.data_ptr(), A, V, Cn, rast.data_ptr(), _tri_ptr(tri), B, H, W, g.data_ptr(),
                                                         grad_attr.data_ptr(), None if grad_rast is None else grad_rast.data_ptr(),
                                                         _stream_ptr(rast.device)))
         return grad_attr, grad_rast, None
