@@ -186,7 +186,6 @@ int tsamd_graph_create(tsamd_handle *h, const float *x_dev, const float *grad_ou
 int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream);
 void tsamd_graph_destroy(tsamd_graph *graph);
 
-/* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
 /* n_iters optimisation steps as ONE HIP graph: per step the evaluation above (energy into energy_ring_dev[k], gradient into
  * grad_dev, upstream gradient 1) followed by tsamd_adam_uniform_step on param_dev with that gradient -- the sequence
  * loss.backward(); optimizer.step() of /root/reference/trainer.py:130-133 for a loss that is the energy alone, with nothing on
@@ -202,6 +201,8 @@ int tsamd_train_loop_create(tsamd_handle *h, float *param_dev, float *grad_dev, 
 int tsamd_train_loop_launch(tsamd_train_loop *loop, const float *c1, const float *c2, const int32_t *order, float lr, float beta1, float beta2,
                             int64_t first_step, const float *grad_limit, void *stream);
 void tsamd_train_loop_destroy(tsamd_train_loop *loop);
+
+/* Blocking read of the last evaluation's (E_s, E_b) in double, for diagnostics. */
 int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
 
 /*
@@ -212,15 +213,6 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2);
  */
 int tsamd_set_timing(tsamd_handle *h, int enable);
 int tsamd_get_timing(tsamd_handle *h, double *tile_kernel_ms, double *finish_kernel_ms, int64_t *evaluations);
-
-/* Diagnostic only (tools/ablate.py): switch parts of the tile kernel off to price them.
- * Any nonzero value makes results WRONG; production code never calls this. */
-int tsamd_debug_set_ablation(tsamd_handle *h, int flags);
-/* Diagnostic only, meaningful in -DTSAMD_ABLATION builds: the first call arms 16 shader-clock
- * stamps per wave (phase boundaries seen by lane 0 of each of up to 16 waves of a workgroup), later calls
- * copy the stamps of the most recent evaluation to host_out (capacity >= 256 * n_tiles,
- * index (16 * tile + wave) * 16 + stamp). */
-int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capacity);
 
 /* out[i] = in[i] * (*scalar_dev); in == out allowed. */
 int tsamd_scale(const float *in_dev, const float *scalar_dev, float *out_dev, int64_t n, void *stream);
@@ -283,44 +275,6 @@ int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev
                                   const float *grad_nrm_dev, void *workspace_dev, void *stream, float *grad_v_pos_dev);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Streaming tiles (EXPERIMENTAL, round 3): the same energy and gradient as tsamd_forward_backward -- same reference
- * entry points replaced, tet_spheres_cuda.cu:118-263 -- from another plan and another tile kernel.  A tet-sphere is cut
- * into a few tubes, each swept level by level (breadth-first over face adjacency: neighbours are within +-1 level) with
- * a rolling window of band records in LDS and four wave groups running four stages on four bands per barrier interval
- * (tssplat_amd/csrc/stream_plan.h).  1.08 instead of 1.28 tile slots per tet on the headline scene.  Its own handle
- * type; tsamd_create / TetSpheres remain the product path: measured on the headline scene this path takes 0.73 ms
- * against 0.43 ms (profiles/r03_experiments.md).  Built-in uniform
- * operator only.  TSAMD_ERR_TILING = a component cannot be cut into tubes whose widest level fits a band: use tsamd_create.
- */
-typedef struct tsamd_stream tsamd_stream;
-typedef struct tsamd_stream_plan_info {
-    int64_t n_vertices, n_tets, n_components, n_tubes;
-    int64_t total_slots;           /* owned + side-halo tets over all tubes                         */
-    int64_t total_bands, total_pairs, total_chunks;
-    int64_t shared_vertex_copies, finish_vertices;
-    int64_t device_bytes, blob_bytes;
-    int32_t max_vertex_slots, max_bands, band_slots, lds_bytes;
-} tsamd_stream_plan_info;
-/* One tube as host pointers into the handle (tests replay exactly the data the kernel consumes; layout: stream_plan.h). */
-typedef struct tsamd_stream_tube_view {
-    int32_t n_bands, n_vslots, n_owned, n_slots;
-    const uint8_t *blob;         /* n_bands band descriptors (24 B each), then the bands' planes and lists */
-    int64_t blob_bytes;
-    const int32_t *slot_tet;     /* n_bands x band_slots global tet ids (-1 = padding)              */
-} tsamd_stream_tube_view;
-int tsamd_stream_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets, int32_t device,
-                        int32_t host_only, int32_t num_threads, tsamd_stream **out);
-void tsamd_stream_destroy(tsamd_stream *h);
-int tsamd_stream_info(const tsamd_stream *h, tsamd_stream_plan_info *out);
-int tsamd_stream_get_tube(const tsamd_stream *h, int64_t tube, tsamd_stream_tube_view *out);
-int tsamd_stream_get_finish_lists(const tsamd_stream *h, int64_t *n_finish, int64_t *n_stage, const int32_t **vid, const int32_t **off);
-int tsamd_stream_forward_backward(tsamd_stream *h, const float *x_dev, const float *grad_out_dev, float c1, float c2, int order,
-                                  void *stream, float *energy_dev, float *grad_dev);
-int tsamd_stream_set_timing(tsamd_stream *h, int enable);
-int tsamd_stream_get_timing(tsamd_stream *h, double *tube_kernel_ms, double *finish_kernel_ms, int64_t *evaluations);
-int tsamd_stream_read_energy_terms(tsamd_stream *h, void *stream, double *terms_host2);
-
-/* ------------------------------------------------------------------------------------------------------------------
  * Renderer slice: the nvdiffrast operators the reference's renderer calls,
  *   tsamd_rasterize            <- dr.rasterize(ctx, pos_clip, tri, resolution=[H, W], grad_db=False)[0]   renderers/mesh_rasterizer.py:103
  *   tsamd_interpolate          <- dr.interpolate(attr, rast, tri)[0]                                     renderers/mesh_rasterizer.py:117,145,153
@@ -330,7 +284,9 @@ int tsamd_stream_read_energy_terms(tsamd_stream *h, void *stream, double *terms_
  * restatement of its published algorithm, fixed in every detail by oracle/raster_oracle.py -- clip-space input, OpenGL
  * conventions (row 0 = bottom), no culling, nearest depth, output (u, v, z/w, triangle_id + 1), 0 = background.  PARITY
  * UNPINNED (no nvdiffrast here).  Not offered: polygon clipping (a triangle with a vertex at w <= 0 is dropped), depth
- * peeling, `ranges`, image-space derivatives (grad_db).  Stateless: the caller owns all buffers and
+ * peeling, `ranges`, image-space derivatives (grad_db).  Limits: height, width <= 8192 (window coordinates are snapped to
+ * 1/256 pixel and kept within +-16384 pixels; a triangle with a vertex beyond that guard band -- or at w <= 0 -- is dropped
+ * whole), n_triangles <= 2^24 - 1 (the id + 1 travels as a float32).  Stateless: the caller owns all buffers and
  * the current HIP device is used.  pos_clip_dev: [batch, n_vertices, 4] f32; tri_dev: [n_triangles, 3] i32;
  * rast: [batch, height, width, 4] f32; attr_dev: [attr_batch (1 or batch), n_vertices, n_channels] f32.
  */
@@ -338,12 +294,15 @@ int tsamd_stream_read_energy_terms(tsamd_stream *h, void *stream, double *terms_
 int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width);
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
                     int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *stream);
+/* A pixel whose id names no triangle of tri_dev (id > n_triangles, e.g. a rast image made with another list) or a triangle
+ * with a vertex index outside [0, n_vertices) is treated as background: zero output, zero gradient, nothing read or written
+ * out of bounds. */
 int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
-                      const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream);
+                      const int32_t *tri_dev, int64_t n_triangles, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream);
 /* grad_attr_dev ([attr_batch, n_vertices, n_channels]) is zero-filled and accumulated by the call; grad_rast_dev
  * ([batch, height, width, 4], channels 2-3 = 0) may be NULL. */
 int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
-                               const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
+                               const int32_t *tri_dev, int64_t n_triangles, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
                                float *grad_attr_dev, float *grad_rast_dev, void *stream);
 
 /* Gradient of tsamd_rasterize w.r.t. pos_clip from the gradient of its (u, v) outputs (what flows back from

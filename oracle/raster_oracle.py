@@ -159,6 +159,20 @@ def rasterize(pos_clip: np.ndarray, tri: np.ndarray, resolution) -> np.ndarray:
     return np.stack([resolve(pos_clip[b], tri, rasterize_ids(pos_clip[b], tri, height, width)) for b in range(pos_clip.shape[0])])
 
 
+def _valid_ids(w: np.ndarray, tri: np.ndarray, n_vertices: int):
+    """Triangle id of every pixel and the mask of pixels that name a usable triangle.  Background, an id beyond the triangle
+    list (a ``rast`` image made with another list) and a triangle with a vertex index outside ``[0, n_vertices)`` are all treated
+    as background -- zero output, zero gradient -- which is what nvdiffrast does with them."""
+    w = np.where(np.isfinite(w), w, 0.0)
+    ids = np.clip(w, 0.0, 2.0 ** 24).astype(np.int64) - 1
+    hit = (ids >= 0) & (ids < len(tri))
+    safe = np.where(hit, ids, 0)
+    if len(tri):
+        t = tri[safe]
+        hit &= np.all((t >= 0) & (t < n_vertices), axis=-1)
+    return ids, hit
+
+
 def interpolate(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray) -> np.ndarray:
     """``dr.interpolate(attr, rast, tri)[0]`` (mesh_rasterizer.py:117): ``u a0 + v a1 + (1 - u - v) a2``, 0 on background."""
     attr = np.asarray(attr, dtype=np.float64)
@@ -168,8 +182,7 @@ def interpolate(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray) -> np.ndarr
     out = np.zeros(rast.shape[:3] + (attr.shape[-1],))
     for b in range(B):
         a = attr[b if attr.shape[0] > 1 else 0]
-        ids = rast[b, ..., 3].astype(np.int64) - 1
-        hit = ids >= 0
+        ids, hit = _valid_ids(rast[b, ..., 3], tri, attr.shape[1])
         t = tri[ids[hit]]
         u, v = rast[b, ..., 0][hit][:, None], rast[b, ..., 1][hit][:, None]
         out[b][hit] = u * a[t[:, 0]] + v * a[t[:, 1]] + (1.0 - u - v) * a[t[:, 2]]
@@ -186,8 +199,7 @@ def interpolate_backward(attr: np.ndarray, rast: np.ndarray, tri: np.ndarray, gr
     grad_rast = np.zeros_like(rast)
     for b in range(rast.shape[0]):
         ab = b if attr.shape[0] > 1 else 0
-        ids = rast[b, ..., 3].astype(np.int64) - 1
-        hit = ids >= 0
+        ids, hit = _valid_ids(rast[b, ..., 3], tri, attr.shape[1])
         t = tri[ids[hit]]
         u, v = rast[b, ..., 0][hit][:, None], rast[b, ..., 1][hit][:, None]
         gg = g[b][hit]

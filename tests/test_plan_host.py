@@ -155,10 +155,13 @@ def test_train_loop_abi_checks_arguments():
 
 
 def test_library_exports_every_declared_symbol():
-    """include/tssplat_amd.h is the contract: every function it declares must be exported."""
+    """include/tssplat_amd.h is the contract (tssplat_amd_experimental.h: the diagnostic switches and the parked streaming
+    path, outside the drop-in boundary): every function they declare must be exported."""
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "tssplat_amd.h")).read()
+    assert "tsamd_stream_" not in header and "tsamd_debug_" not in header   # experiments stay out of the product ABI
+    header += open(os.path.join(root, "include", "tssplat_amd_experimental.h")).read()
     declared = set(re.findall(r"\b(tsamd_[a-z0-9_]+)\s*\(", header))
     declared -= {"tsamd_options", "tsamd_plan_info", "tsamd_tile_view", "tsamd_status", "tsamd_handle"}
     lib = C.CDLL(_capi.lib_path())

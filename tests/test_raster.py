@@ -113,8 +113,13 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None) == 1          # null workspace / output
     assert b"null" in lib.tsamd_last_error()
     assert lib.tsamd_rasterize(None, 1, 3, None, 1, 20000, 4, None, None, None) == 1
-    assert lib.tsamd_interpolate(None, 2, 3, 3, None, None, 4, 4, 4, None, None) == 1     # attr_batch neither 1 nor batch
-    assert lib.tsamd_interpolate_backward(None, 1, 3, 0, None, None, 1, 4, 4, None, None, None, None) == 1
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 9000, 4, None, None, None) == 1       # beyond the 8192-pixel guard-band limit
+    assert b"8192" in lib.tsamd_last_error()
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1 << 24, 4, 4, None, None, None) == 1    # ids travel as float32: <= 2^24 - 1 triangles
+    assert b"2^24" in lib.tsamd_last_error()
+    assert lib.tsamd_interpolate(None, 2, 3, 3, None, None, 1, 4, 4, 4, None, None) == 1     # attr_batch neither 1 nor batch
+    assert lib.tsamd_interpolate(None, 1, 3, 3, None, None, -1, 1, 4, 4, None, None) == 1    # negative triangle count
+    assert lib.tsamd_interpolate_backward(None, 1, 3, 0, None, None, 1, 1, 4, 4, None, None, None, None) == 1
     # empty images are fine without any pointer
     assert lib.tsamd_rasterize(None, 0, 0, None, 0, 0, 0, None, None, None) == 0
 
@@ -455,3 +460,46 @@ def test_renderer_operators_on_empty_inputs():
         aa.backward(g)
         assert torch.equal(col.grad, g)
         assert pos.grad is None or float(pos.grad.abs().max()) == 0.0
+
+
+def test_oracle_interpolate_treats_foreign_ids_as_background():
+    """A rast image whose ids do not belong to the triangle list (longer list, corrupt id, NaN) or a triangle with a vertex
+    index outside the attribute array: background in the forward, nothing scattered in the backward."""
+    tri = np.array([[0, 1, 2], [0, 2, 7]], dtype=np.int32)          # second triangle: vertex 7 does not exist
+    attr = np.arange(12, dtype=np.float64).reshape(1, 4, 3)
+    rast = np.zeros((1, 1, 5, 4))
+    rast[0, 0, :, 0] = 0.25
+    rast[0, 0, :, 1] = 0.5
+    rast[0, 0, :, 3] = [1.0, 2.0, 3.0, np.nan, 1e9]                  # ok | bad vertex index | beyond the list | NaN | huge
+    out = R.interpolate(attr, rast, tri)
+    assert np.allclose(out[0, 0, 0], 0.25 * attr[0, 0] + 0.5 * attr[0, 1] + 0.25 * attr[0, 2])
+    assert np.all(out[0, 0, 1:] == 0.0)
+    ga, gr = R.interpolate_backward(attr, rast, tri, np.ones((1, 1, 5, 3)))
+    assert np.all(gr[0, 0, 1:] == 0.0) and np.any(gr[0, 0, 0] != 0.0)
+    assert np.allclose(ga[0].sum(axis=0), 1.0) and np.all(ga[0, 3] == 0.0)   # one pixel's weights, nothing on vertex 3
+
+
+@pytest.mark.gpu
+def test_interpolate_bounds_on_foreign_rast():
+    """tsamd_interpolate* now know the triangle count.  Same cases as the oracle test above, on the device, plus an
+    EMPTY triangle list with a rast image that still carries ids (no dummy index buffer needed any more)."""
+    import torch
+    import tssplat_amd.dr as dr
+    tri_np = np.array([[0, 1, 2], [0, 2, 7]], dtype=np.int32)
+    attr_np = np.arange(12, dtype=np.float32).reshape(1, 4, 3)
+    rast_np = np.zeros((1, 1, 5, 4), dtype=np.float32)
+    rast_np[0, 0, :, 0] = 0.25
+    rast_np[0, 0, :, 1] = 0.5
+    rast_np[0, 0, :, 3] = [1.0, 2.0, 3.0, np.nan, 1e9]
+    attr = torch.from_numpy(attr_np).cuda().requires_grad_(True)
+    rast = torch.from_numpy(rast_np).cuda().requires_grad_(True)
+    out, _ = dr.interpolate(attr, rast, torch.from_numpy(tri_np).cuda())
+    ref = R.interpolate(attr_np, rast_np, tri_np)
+    assert np.allclose(out.detach().cpu().numpy(), ref, atol=1e-6)
+    out.backward(torch.ones_like(out))
+    ga, gr = R.interpolate_backward(attr_np, rast_np, tri_np, np.ones((1, 1, 5, 3)))
+    assert np.allclose(attr.grad.cpu().numpy(), ga, atol=1e-6)
+    assert np.allclose(rast.grad.cpu().numpy(), gr, atol=1e-5)
+    empty = torch.zeros((0, 3), dtype=torch.int32, device="cuda")
+    out0, _ = dr.interpolate(attr.detach(), rast.detach(), empty)
+    assert float(out0.abs().max()) == 0.0

@@ -43,14 +43,16 @@ def main():
     ap.add_argument("--no-conflict-aware", action="store_true")
     ap.add_argument("--rebuild-dminv", action="store_true")
     ap.add_argument("--lds-request", type=int, default=0, help="request this much dynamic LDS per workgroup (limits workgroups per CU)")
+    ap.add_argument("--stamps-only", action="store_true", help="production kernel + stamps (-DTSAMD_STAMPS): no switches, no mask sweep")
     args = ap.parse_args()
     if args.lds_request:
         os.environ["TSAMD_LDS_REQUEST"] = str(args.lds_request)
     # the production library has the switches compiled out; build / select the ablation variant
     from tssplat_amd import _build
-    variant = os.path.join(os.path.dirname(_build.LIB), "libtssplat_amd_ablation.so")
+    vname, vflag = ("stamps", "-DTSAMD_STAMPS") if args.stamps_only else ("ablation", "-DTSAMD_ABLATION")
+    variant = os.path.join(os.path.dirname(_build.LIB), f"libtssplat_amd_{vname}.so")
     if not os.path.exists(variant):
-        variant = _build.build_variant("ablation", ["-DTSAMD_ABLATION"])
+        variant = _build.build_variant(vname, [vflag])
     os.environ.setdefault("TSSPLAT_AMD_LIB", variant)
     import torch
     from tssplat_amd import _capi, scenes, tet_spheres_ext as T
@@ -66,6 +68,8 @@ def main():
     e = torch.empty((), device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     masks = MASKS if not args.masks else [(int(m), "custom") for m in args.masks.split(",")]
+    if args.stamps_only:
+        masks = [(0, "production kernel + stamps (unarmed)")]
     out = {"scene": f"{args.spheres} x {args.scene}", "m": sc.n_tets, "n": sc.n_vertices, "plan": info, "rows": []}
     for mask, what in masks:
         _capi.check(lib.tsamd_debug_set_ablation(ts._handle(), mask))
@@ -109,6 +113,35 @@ def main():
     # arrival spread at every stamp: last wave minus first wave (what a barrier right after it costs the early ones)
     spread = clk.max(axis=1) - clk.min(axis=1)
     print("arrival spread (last wave - first wave) at each stamp: " + ", ".join(f"{spread[:, k].mean():.0f}" for k in range(10)))
+    if args.stamps_only:
+        # sub-stamps (cycles since the wave's first instruction, mean over tiles; waves 0, 5, 10):
+        #   10 descriptor + vertex id arrived, position loads issued | 11 positions arrived | 1 barrier: positions staged |
+        #   12 planes arrived + first F stored | 13 this wave's pass 1 done | 2 barrier | ... 4 H written | 14 first slot of pass 3 done | 5 pass 3 done
+        order = [10, 11, 1, 12, 13, 2, 3, 4, 14, 5, 6, 7, 8, 9]
+        rel = raw - raw[:, :, 0:1]
+        for w in sorted({0, min(5, nw - 1), max(nw - 2, 0)}):
+            print(f"wave {w:2d} cumulative: " + "  ".join(f"s{k}={rel[:, w, k].mean():.0f}" for k in order))
+        out["substamps_cumulative_wave0"] = {str(k): float(rel[:, 0, k].mean()) for k in order}
+        # are the workgroups of a launch in step with each other?  start time of every tile relative to the launch, and the
+        # distribution of the memory phase (stamp 2 - stamp 0) over the launch
+        start = raw[:, 0, 0] - raw[:, 0, 0].min()
+        mem = raw[:, 0, 2] - raw[:, 0, 0]
+        life = raw[:, 0, 9] - raw[:, 0, 0]
+        qs = [0, 10, 25, 50, 75, 90, 100]
+        print("memory phase (entry -> pass 1 done), percentiles over tiles: " + ", ".join(f"p{q}={np.percentile(mem, q):.0f}" for q in qs))
+        print("workgroup lifetime, percentiles over tiles: " + ", ".join(f"p{q}={np.percentile(life, q):.0f}" for q in qs))
+        print(f"launch span {start.max() + life[np.argmax(start)]:.0f} cycles")
+        # tiles in their memory phase over time (64 bins across the launch): a convoy shows as a wave pattern
+        t_end = (raw[:, 0, 9]).max() - raw[:, 0, 0].min()
+        bins = np.linspace(0, t_end, 65)
+        s0 = raw[:, 0, 0] - raw[:, 0, 0].min()
+        s2 = raw[:, 0, 2] - raw[:, 0, 0].min()
+        s9 = raw[:, 0, 9] - raw[:, 0, 0].min()
+        mids = 0.5 * (bins[1:] + bins[:-1])
+        in_mem = [(int(((s0 <= t) & (t < s2)).sum()), int(((s2 <= t) & (t < s9)).sum())) for t in mids]
+        print("resident workgroups in (memory phase, compute phases) at 64 instants across the launch:")
+        print(" ".join(f"{a}/{b}" for a, b in in_mem))
+        out["residency_over_time"] = in_mem
     print(json.dumps(out))
 
 

@@ -21,7 +21,8 @@ ARCH = "gfx950"
 
 SOURCES = ["plan.cpp", "conflict_opt.cpp", "stream_plan.cpp", "stream_capi.cpp", "capi.cpp", "kernels.hip", "stream_kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
            "raster_capi.cpp", "raster_kernels.hip", "aa_kernels.hip"]
-HEADERS = ["plan.h", "conflict_opt.h", "stream_plan.h", "stream_kernels.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
+HEADERS = ["plan.h", "conflict_opt.h", "stream_plan.h", "stream_kernels.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h"),
+           os.path.join("..", "..", "include", "tssplat_amd_experimental.h")]
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]
 # -fno-slp-vectorize: SLP packs the 3x3 algebra into v_pk_*_f32, which runs at the scalar-fp32 rate on

@@ -6,7 +6,7 @@
 // tiling plan's planes, the staging rows for shared vertices and the per-tile
 // energy partials.  Unlike the reference destructor (tet_spheres.cpp:128-138)
 // everything allocated is freed.
-#include "../../include/tssplat_amd.h"
+#include "../../include/tssplat_amd_experimental.h"   // (includes tssplat_amd.h)
 
 #include <hip/hip_runtime_api.h>
 

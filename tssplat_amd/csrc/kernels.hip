@@ -298,6 +298,15 @@ enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_
     do {                                                                  \
         if (a.clk && (threadIdx.x & 63) == 0) a.clk[(16 * size_t(tile) + (threadIdx.x >> 6)) * 16 + (k)] = clock64(); \
     } while (0)
+#elif defined(TSAMD_STAMPS)      // the production kernel + the shader-clock stamps, no switches (tools/ablate.py --stamps-only)
+#define DBG(flag) false
+#define STAMP(k)                                                          \
+    do {                                                                  \
+        if (a.clk && (threadIdx.x & 63) == 0) a.clk[(16 * size_t(tile) + (threadIdx.x >> 6)) * 16 + (k)] = clock64(); \
+    } while (0)
+#elif defined(TSAMD_FORCE_DBG)   // pricing builds: an ablation switch as a compile-time constant, no stamps (tools/ab_variants.py)
+#define DBG(flag) (((TSAMD_FORCE_DBG) & (flag)) != 0)
+#define STAMP(k) ((void)0)
 #else
 #define DBG(flag) false
 #define STAMP(k) ((void)0)
@@ -361,6 +370,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * lt); };
     auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * lt); };
     STAMP(0);
+#ifdef TSAMD_SLEEP_BODY   // pipeline-model probe: idle cycles at the head of the tile body (descriptor requested, no plane load issued yet)
+    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_BODY);
+#endif
     // The position gather is a chain of two dependent loads (vertex id, then x).  vmcnt retires in order, so the
     // id load goes out FIRST: the wait for it then does not include the 13 plane loads, and the x loads travel
     // together with the planes instead of behind them.
@@ -368,6 +380,69 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     gv0 = g_gvid[td.vert_off + (tid < td.n_verts ? tid : 0)];
 #endif
     // (otherwise the id was requested by the kernel's first instructions, ahead of the descriptor fetch -- see there)
+#ifndef TSAMD_OLD_LOAD_ORDER
+    // ---- stream the tile ----
+    // A CU pulls cold data at ~11 bytes per cycle whatever the rest of the chip does (tools/ubench_ingest.hip: one workgroup
+    // alone gets 10-12 B/cycle, two on a CU share the same 11), in the order the loads were issued, wave after wave.  The
+    // order below is built around that FIFO:
+    //   1. (kernel entry) the vertex ids;  2. the two vertex-offset planes -- 12 KB per workgroup, about what the id's latency covers;
+    //   3. the positions, as soon as the ids are back: they reach the LDS behind 12 KB instead of behind the whole 80 KB, so the
+    //      barrier that publishes them falls EARLY in the stream, not at its end;
+    //   4. the nine Dm^-1 planes: every wave computes its F as soon as ITS planes have landed -- wave 0 long before wave 11 --
+    //      so pass 1 runs inside the delivery window instead of behind it;
+    //   5. the neighbour planes (and an explicit operator's weights), which nobody needs before pass 2, go out after the
+    //      barrier: 8 (44 with an operator) of the 52 (88) bytes per slot are off the path to the first F.
+    // (Before: ids, all 13 planes, positions; the positions then arrived last, the barrier fell at ~6.5 k cycles and the whole
+    // of pass 1 -- 4.5 k cycles, every wave at once -- came after the last byte.)
+    VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01, q_nb23;
+    VF dm[9];
+    constexpr int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? kPlanesWeighted : kPlanes);
+    // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
+    unsigned char *rs = xs + 16 * VP;
+    const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
+        reinterpret_cast<const GLOBAL_AS unsigned char *>(pl) +
+        ((size_t(kBasePlanes) * td.s_pad * 4 + size_t(td.n_inc4) * 8 + 2 * (size_t(td.n_verts) + 1) + 15) & ~size_t(15)));
+    v4f rest0 = v4f{0.f, 0.f, 0.f, 0.f};
+    if (REBUILD) rest0 = g_rest[tid < td.n_verts ? tid : 0];
+    // the positions: unconditional loads (lanes beyond the tile's vertices hold vertex 0 and do not store), so that the
+    // stream stays straight-line code whose waits the compiler can count
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" : "+v"(gv0));  // (the wait for the id lands here: vmcnt(2), the two offset planes stay in flight)
+    float px, py, pz;
+    {
+        const size_t gv = size_t(gv0) * 3;
+        px = g_x[gv], py = g_x[gv + 1], pz = g_x[gv + 2];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!REBUILD) {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(10);   // (stamps builds) everything on the path to the first F is requested
+    if (tid < td.n_verts) {
+        reinterpret_cast<float4 *>(xs)[tid] = make_float4(px, py, pz, 0.f);   // (waits for the positions only: vmcnt(9))
+        if (REBUILD) reinterpret_cast<v4f *>(rs)[tid] = rest0;
+    }
+    for (int v = tid + nthr; v < td.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
+        const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
+        reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
+        if (REBUILD) reinterpret_cast<v4f *>(rs)[v] = g_rest[v];
+    }
+    STAMP(11);   // this wave's positions are in the LDS
+    __syncthreads();
+    // behind the barrier: what pass 2 needs
+    q_nb01 = plane_u(2), q_nb23 = plane_u(3);
+    // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
+    // weights for pass 3 replace them after pass 2
+    VF wd, wk[4];
+    if (WEIGHTED) {
+        wd = plane_f(13);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#else
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     VF dm[9];
@@ -408,6 +483,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         if (REBUILD) reinterpret_cast<v4f *>(rs)[v] = g_rest[v];
     }
     __syncthreads();
+#endif
     STAMP(1);
     if (DBG(DBG_EXIT_AFTER_LOAD)) {
         float chk = (REBUILD ? rest0.x : dm[0][0] + dm[4][1] + dm[8][SPT - 1]) + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
@@ -468,9 +544,18 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             }
             store_slot(smem, t_own[p], F);
             SLOT_FENCE();
+#ifdef TSAMD_STAMPS
+            if (p == 0) STAMP(12);   // planes arrived, F of the first slot stored
+#endif
         }
     }
+#ifdef TSAMD_STAMPS
+    STAMP(13);   // this wave's pass 1 done (before the barrier)
+#endif
     __syncthreads();
+#ifdef TSAMD_SLEEP_MID
+    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_MID);
+#endif
     STAMP(2);  // pass 1 done
     if (DBG(DBG_EXIT_AFTER_P1)) {
         if (e_b == 12345.678f) g_partials[0] = e_b;
@@ -661,6 +746,12 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                         D[p][3 * k + i] = P[3 * i + 0] * dm[3 * k + 0][p] + P[3 * i + 1] * dm[3 * k + 1][p] +
                                           P[3 * i + 2] * dm[3 * k + 2][p];
                 SLOT_FENCE();
+#ifdef TSAMD_STAMPS
+                if (p == 0) {
+                    asm volatile("" : : "v"(D[0][0]), "v"(D[0][4]), "v"(D[0][8]));
+                    STAMP(14);   // first slot of pass 3 done
+                }
+#endif
             }
         } else {
 #pragma unroll
@@ -759,6 +850,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         }
     }
 
+#ifdef TSAMD_SLEEP_END
+    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_END);
+#endif
     STAMP(8);  // vertex gather + stores done (this wave): nothing is left to do, the wave ends here
 #ifdef TSAMD_ABLATION
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamp 9 - stamp 8 = what s_endpgm waits for: the result stores' acknowledgement

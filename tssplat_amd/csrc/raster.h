@@ -23,10 +23,10 @@ hipError_t launch_antialias_backward(const float *color, const float *rast, cons
                                      int64_t n_vertices, int64_t n_tri, int height, int width, int channels, const float *grad_out, float boost,
                                      float *grad_color, float *grad_pos, hipStream_t stream);
 hipError_t launch_interpolate(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
-                              int64_t batch, int height, int width, float *out, hipStream_t stream);
+                              int64_t n_tri, int64_t batch, int height, int width, float *out, hipStream_t stream);
 // grad_attr is zero-filled by the launch; grad_rast may be null
 hipError_t launch_interpolate_backward(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
-                                       int64_t batch, int height, int width, const float *grad_out, float *grad_attr, float *grad_rast,
+                                       int64_t n_tri, int64_t batch, int height, int width, const float *grad_out, float *grad_attr, float *grad_rast,
                                        hipStream_t stream);
 
 }  // namespace tsamd

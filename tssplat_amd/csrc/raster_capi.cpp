@@ -12,8 +12,10 @@ namespace {
 
 int check_image(int64_t batch, int32_t height, int32_t width)
 {
-    if (batch < 0 || height < 0 || width < 0 || height > 16384 || width > 16384)
-        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch / height / width out of range (0 .. 16384 pixels per side)");
+    // 8192: snapped window coordinates are kept within +-2^22 sub-pixel units (1/256 pixel) = +-16384 pixels and a triangle with a
+    // vertex beyond that is dropped (there is no clipping), so the cap leaves a guard band of at least one screen on every side
+    if (batch < 0 || height < 0 || width < 0 || height > 8192 || width > 8192)
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch / height / width out of range (0 .. 8192 pixels per side)");
     return TSAMD_OK;
 }
 
@@ -32,8 +34,8 @@ int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices
 {
     int rc = check_image(batch, height, width);
     if (rc) return rc;
-    if (n_vertices < 0 || n_triangles < 0 || n_triangles >= (int64_t(1) << 32) - 1)
-        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or more than 2^32 - 2 triangles (the id shares a 64-bit key with the depth)");
+    if (n_vertices < 0 || n_triangles < 0 || n_triangles > (int64_t(1) << 24) - 1)
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or more than 2^24 - 1 triangles (the id + 1 is returned as a float32, exact up to 2^24)");
     if (batch * ((n_triangles + 255) / 256) > int64_t(INT32_MAX))
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch x triangles / 256 exceeds the grid limit (2^31 - 1 workgroups)");
     const int64_t pixels = batch * int64_t(height) * width;
@@ -45,31 +47,33 @@ int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices
 }
 
 int tsamd_interpolate(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
-                      const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream)
+                      const int32_t *tri_dev, int64_t n_triangles, int64_t batch, int32_t height, int32_t width, float *out_dev, void *stream)
 {
     int rc = check_image(batch, height, width);
     if (rc) return rc;
-    if (n_vertices < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
-        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1");
+    if (n_vertices < 0 || n_triangles < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1, sizes >= 0");
     const int64_t pixels = batch * int64_t(height) * width;
-    if (pixels > 0 && (!attr_dev || !rast_dev || !tri_dev || !out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
-    TSAMD_HIP(tsamd::launch_interpolate(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, batch, height, width, out_dev,
+    if (pixels > 0 && (!rast_dev || !out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "rast_dev / out_dev is null");
+    if (pixels > 0 && n_triangles > 0 && (!attr_dev || !tri_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_dev / tri_dev is null");
+    TSAMD_HIP(tsamd::launch_interpolate(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, n_triangles, batch, height, width, out_dev,
                                         static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }
 
 int tsamd_interpolate_backward(const float *attr_dev, int64_t attr_batch, int64_t n_vertices, int32_t n_channels, const float *rast_dev,
-                               const int32_t *tri_dev, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
+                               const int32_t *tri_dev, int64_t n_triangles, int64_t batch, int32_t height, int32_t width, const float *grad_out_dev,
                                float *grad_attr_dev, float *grad_rast_dev, void *stream)
 {
     int rc = check_image(batch, height, width);
     if (rc) return rc;
-    if (n_vertices < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
-        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1");
+    if (n_vertices < 0 || n_triangles < 0 || n_channels < 1 || (attr_batch != 1 && attr_batch != batch))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_batch must be 1 or batch, n_channels >= 1, sizes >= 0");
     const int64_t pixels = batch * int64_t(height) * width;
     if (attr_batch * n_vertices > 0 && !grad_attr_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "grad_attr_dev is null");
-    if (pixels > 0 && (!attr_dev || !rast_dev || !tri_dev || !grad_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "null device pointer");
-    TSAMD_HIP(tsamd::launch_interpolate_backward(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, batch, height, width,
+    if (pixels > 0 && (!rast_dev || !grad_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "rast_dev / grad_out_dev is null");
+    if (pixels > 0 && n_triangles > 0 && (!attr_dev || !tri_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "attr_dev / tri_dev is null");
+    TSAMD_HIP(tsamd::launch_interpolate_backward(attr_dev, attr_batch, n_vertices, n_channels, rast_dev, tri_dev, n_triangles, batch, height, width,
                                                  grad_out_dev, grad_attr_dev, grad_rast_dev, static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }

@@ -96,7 +96,7 @@ __device__ __forceinline__ void drain(WaveQueue &q, int lane)
             const int k = base + 64 * j + lane;
             const bool have = k < q.count;
             key[j] = have ? q.keys[have ? k : 0] : kNoFragment;
-            slot[j] = q.image + (have ? q.pixels[k] : uint32_t(lane));   // (an empty lane reads a harmless pixel: the load stays unconditional)
+            slot[j] = q.image + (have ? q.pixels[k] : 0u);   // (an empty lane reads pixel 0 of its view, which always exists: the load stays unconditional)
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -376,21 +376,40 @@ __global__ __launch_bounds__(256) void rasterize_backward_kernel(const float4 *p
     }
 }
 
+// Triangle named by a rast pixel's fourth channel (id + 1 as a float, exact up to 2^24 - 1 triangles: tsamd_rasterize
+// refuses longer lists), or -1 for background / an id outside [0, n_tri) / a non-finite value.
+__device__ __forceinline__ int64_t triangle_of(float w, int64_t n_tri)
+{
+    if (!(w >= 1.f) || !(w <= 16777216.f)) return -1;
+    const int64_t t = int64_t(w) - 1;
+    return t < n_tri ? t : -1;
+}
+// The three vertex indices of triangle t; false when one of them lies outside [0, n_vertices).
+__device__ __forceinline__ bool triangle_indices(const int32_t *tri, int64_t t, int64_t n_vertices, int32_t &i0, int32_t &i1, int32_t &i2)
+{
+    i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    return uint64_t(i0) < uint64_t(n_vertices) && uint64_t(i1) < uint64_t(n_vertices) && uint64_t(i2) < uint64_t(n_vertices)
+           && i0 >= 0 && i1 >= 0 && i2 >= 0;
+}
+
 __global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
-                                                          const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw, float *out)
+                                                          const float4 *rast, const int32_t *tri, int64_t n_tri, int64_t batch, int64_t hw, float *out)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (gid >= batch * hw) return;
     const float4 r = rast[gid];
     float *o = out + gid * channels;
-    const int64_t t = int64_t(r.w) - 1;
-    if (t < 0) {
+    const int64_t t = triangle_of(r.w, n_tri);
+    int32_t i0 = 0, i1 = 0, i2 = 0;
+    // a pixel whose id names no triangle of THIS list, or a triangle with a vertex index outside the attribute array, is
+    // background (what nvdiffrast does with them): the rast image may come from another triangle list, or from the caller
+    if (t < 0 || !triangle_indices(tri, t, n_vertices, i0, i1, i2)) {
         for (int c = 0; c < channels; ++c) o[c] = 0.f;
         return;
     }
     const int64_t b = gid / hw;
     const float *a = attr + (attr_batch > 1 ? b : 0) * n_vertices * channels;
-    const float *a0 = a + int64_t(tri[3 * t]) * channels, *a1 = a + int64_t(tri[3 * t + 1]) * channels, *a2 = a + int64_t(tri[3 * t + 2]) * channels;
+    const float *a0 = a + int64_t(i0) * channels, *a1 = a + int64_t(i1) * channels, *a2 = a + int64_t(i2) * channels;
     const float u = r.x, v = r.y, w = 1.f - r.x - r.y;
     for (int c = 0; c < channels; ++c) o[c] = u * a0[c] + v * a1[c] + w * a2[c];
 }
@@ -399,20 +418,21 @@ __global__ __launch_bounds__(256) void interpolate_kernel(const float *attr, int
 // global atomics: the order of the additions, and so the last bits of the result, vary from run to run -- like nvdiffrast's
 // own backward); d out / d (u, v) per pixel.
 __global__ __launch_bounds__(256) void interpolate_backward_kernel(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels,
-                                                                   const float4 *rast, const int32_t *tri, int64_t batch, int64_t hw,
+                                                                   const float4 *rast, const int32_t *tri, int64_t n_tri, int64_t batch, int64_t hw,
                                                                    const float *grad_out, float *grad_attr, float4 *grad_rast)
 {
     const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const bool inside = gid < batch * hw;
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) r = rast[gid];
-    const int64_t t = int64_t(r.w) - 1;
-    const bool valid = inside && t >= 0;
+    const int64_t t = triangle_of(r.w, n_tri);
+    int32_t i0 = 0, i1 = 0, i2 = 0;
+    const bool valid = inside && t >= 0 && triangle_indices(tri, t, n_vertices, i0, i1, i2);   // (else background: no reads, no atomics)
     if (inside && !valid && grad_rast) grad_rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t b = valid ? gid / hw : 0;
     const int64_t base = (attr_batch > 1 ? b : 0) * n_vertices * channels;
     int64_t o0 = 0, o1 = 0, o2 = 0;
-    if (valid) o0 = base + int64_t(tri[3 * t]) * channels, o1 = base + int64_t(tri[3 * t + 1]) * channels, o2 = base + int64_t(tri[3 * t + 2]) * channels;
+    if (valid) o0 = base + int64_t(i0) * channels, o1 = base + int64_t(i1) * channels, o2 = base + int64_t(i2) * channels;
     const float u = r.x, v = r.y, w = 1.f - r.x - r.y;
     // lanes of one triangle (and attribute batch) in a row: one set of atomics per run
     const Runs runs = find_runs(valid ? (attr_batch > 1 ? b : 0) * (int64_t(1) << 32) + t : -1 - int64_t(threadIdx.x));
@@ -477,17 +497,17 @@ hipError_t launch_rasterize_backward(const float *pos_clip, int64_t batch, int64
 }
 
 hipError_t launch_interpolate(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
-                              int64_t batch, int height, int width, float *out, hipStream_t stream)
+                              int64_t n_tri, int64_t batch, int height, int width, float *out, hipStream_t stream)
 {
     const int64_t hw = int64_t(height) * width;
     if (batch * hw <= 0) return hipSuccess;
     hipLaunchKernelGGL(interpolate_kernel, dim3(blocks_for(batch * hw)), dim3(256), 0, stream, attr, attr_batch, n_vertices, channels,
-                       reinterpret_cast<const float4 *>(rast), tri, batch, hw, out);
+                       reinterpret_cast<const float4 *>(rast), tri, n_tri, batch, hw, out);
     return hipGetLastError();
 }
 
 hipError_t launch_interpolate_backward(const float *attr, int64_t attr_batch, int64_t n_vertices, int channels, const float *rast, const int32_t *tri,
-                                       int64_t batch, int height, int width, const float *grad_out, float *grad_attr, float *grad_rast,
+                                       int64_t n_tri, int64_t batch, int height, int width, const float *grad_out, float *grad_attr, float *grad_rast,
                                        hipStream_t stream)
 {
     const int64_t hw = int64_t(height) * width;
@@ -495,7 +515,7 @@ hipError_t launch_interpolate_backward(const float *attr, int64_t attr_batch, in
     if (e != hipSuccess) return e;
     if (batch * hw <= 0) return hipSuccess;
     hipLaunchKernelGGL(interpolate_backward_kernel, dim3(blocks_for(batch * hw)), dim3(256), 0, stream, attr, attr_batch, n_vertices, channels,
-                       reinterpret_cast<const float4 *>(rast), tri, batch, hw, grad_out, grad_attr, reinterpret_cast<float4 *>(grad_rast));
+                       reinterpret_cast<const float4 *>(rast), tri, n_tri, batch, hw, grad_out, grad_attr, reinterpret_cast<float4 *>(grad_rast));
     return hipGetLastError();
 }
 

@@ -52,20 +52,6 @@ def _check_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-_dummy_tri: dict = {}
-
-
-def _tri_ptr(tri: torch.Tensor) -> int:
-    """Device address of the index list; an EMPTY list has none (torch hands out 0), and tsamd_interpolate -- which is not told
-    the triangle count -- rejects a null pointer: a three-entry dummy stands in (no pixel of `rast` can refer to it)."""
-    if tri.numel() > 0:
-        return tri.data_ptr()
-    d = _dummy_tri.get(tri.device)
-    if d is None:
-        d = _dummy_tri[tri.device] = torch.zeros(3, dtype=torch.int32, device=tri.device)
-    return d.data_ptr()
-
-
 def _check_tri(tri: torch.Tensor, device) -> torch.Tensor:
     if not isinstance(tri, torch.Tensor) or tri.dim() != 2 or tri.shape[1] != 3:
         raise RuntimeError("tssplat_amd.dr: tri must be an [T, 3] tensor")
@@ -114,6 +100,13 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
         raise RuntimeError("tssplat_amd.dr.rasterize: pos must be [B, V, 4] clip-space positions (instanced mode)")
     tri = _check_tri(tri, pos.device)
     height, width = int(resolution[0]), int(resolution[1])
+    # limits of this slice (include/tssplat_amd.h): the triangle id + 1 travels as a float32 (exact up to 2^24), and window
+    # coordinates are snapped within +-16384 pixels -- a triangle with a vertex beyond that guard band, or at w <= 0, is dropped
+    # whole (nvdiffrast clips): harmless for objects inside the frustum, which is what the reference renders
+    if int(tri.shape[0]) > (1 << 24) - 1:
+        raise RuntimeError("tssplat_amd.dr.rasterize: more than 2^24 - 1 triangles")
+    if not (0 <= height <= 8192 and 0 <= width <= 8192):
+        raise RuntimeError("tssplat_amd.dr.rasterize: resolution out of range (0 .. 8192 pixels per side)")
     rast = _RasterizeFunc.apply(pos, tri, glctx, height, width)
     return rast, torch.empty((int(pos.shape[0]), height, width, 0), dtype=torch.float32, device=pos.device)
 
@@ -125,7 +118,7 @@ class _InterpolateFunc(torch.autograd.Function):
         A, V, Cn = int(attr.shape[0]), int(attr.shape[1]), int(attr.shape[2])
         out = torch.empty((B, H, W, Cn), dtype=torch.float32, device=rast.device)
         with _device_ctx(rast.device):
-            _capi.check(_lib.tsamd_interpolate(attr.data_ptr(), A, V, Cn, rast.data_ptr(), _tri_ptr(tri), B, H, W, out.data_ptr(),
+            _capi.check(_lib.tsamd_interpolate(attr.data_ptr(), A, V, Cn, rast.data_ptr(), tri.data_ptr(), int(tri.shape[0]), B, H, W, out.data_ptr(),
                                                _stream_ptr(rast.device)))
         ctx.save_for_backward(attr, rast, tri)
         return out
@@ -139,7 +132,7 @@ class _InterpolateFunc(torch.autograd.Function):
         grad_attr = torch.empty_like(attr)
         grad_rast = torch.empty_like(rast) if ctx.needs_input_grad[1] else None
         with _device_ctx(rast.device):
-            _capi.check(_lib.tsamd_interpolate_backward(attr.data_ptr(), A, V, Cn, rast.data_ptr(), _tri_ptr(tri), B, H, W, g.data_ptr(),
+            _capi.check(_lib.tsamd_interpolate_backward(attr.data_ptr(), A, V, Cn, rast.data_ptr(), tri.data_ptr(), int(tri.shape[0]), B, H, W, g.data_ptr(),
                                                         grad_attr.data_ptr(), None if grad_rast is None else grad_rast.data_ptr(),
                                                         _stream_ptr(rast.device)))
         return grad_attr, grad_rast, None
