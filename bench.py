@@ -463,16 +463,24 @@ def _run_rank(args, stdout_fd: int) -> None:
     finish_ms /= max(n_eval, 1)
     b_alg = 68.0 * m_local + 24.0 * n_local           # bytes per fused fwd+bwd evaluation
     achieved = b_alg / (tile_ms * 1e-3) / 1e9 if tile_ms > 0 else 0.0
-    traffic = None
-    prof = os.path.join(ROOT, "profiles", "traffic.json")   # written from rocprofv3 --pmc passes, see profiles/README.md
+    # HBM bytes per launch from the PMC counters cannot be collected inside this process (rocprofv3 wraps the command: separate
+    # --pmc passes, tools/profile_round.sh); the figure of the last profiled run is reported only while the kernel and the plan
+    # layout it was measured on are the ones running now (fingerprint of kernels.hip + plan.cpp + plan.h), otherwise null
+    traffic, traffic_note = None, "no PMC pass on record for this workload (tools/profile_round.sh)"
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(prof):
         try:
-            rec = json.load(open(prof))
-            key = f"{args.scene}x{my_spheres}"
-            if key in rec:
-                traffic = rec[key]["hbm_bytes_per_launch"]
-        except Exception:                              # noqa: BLE001
-            traffic = None
+            from tssplat_amd import _build
+            rec = json.load(open(prof)).get(f"{args.scene}x{my_spheres}")
+            if rec is not None:
+                if rec.get("sources") == _build.traffic_digest():
+                    traffic, traffic_note = rec["hbm_bytes_per_launch"], f"rocprofv3 PMC passes of {rec['round']}, same kernel and plan sources"
+                else:
+                    traffic_note = (f"dropped: profiles/traffic.json ({rec.get('round')}) was measured on other kernel / plan sources "
+                                    f"({rec.get('sources', 'unstamped')} != {_build.traffic_digest()}); re-run tools/profile_round.sh")
+                    print("bench.py: " + traffic_note, file=sys.stderr)
+        except Exception as exc:                       # noqa: BLE001
+            traffic, traffic_note = None, f"profiles/traffic.json unreadable: {exc}"
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     for _ in range(args.steps):
@@ -530,9 +538,16 @@ def _run_rank(args, stdout_fd: int) -> None:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_launch": b_alg,
                 "kernel_ms": tile_ms,
                 "finish_kernel_ms": finish_ms,
+                "launches": int(n_eval),               # evaluations behind kernel_ms (at least 50, whatever --steps says)
+                # SURVEY 8(d) defines the roofline on t(fwd+bwd), i.e. on the whole step -- tile kernel + finish kernel +
+                # whatever the launch path adds -- not on the dominant kernel alone: this rank's bytes / the timed step
+                "achieved_step": b_alg / (elapsed / args.steps) / 1e9,
+                "frac_step": b_alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "frac_kernels": b_alg / ((tile_ms + finish_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS if tile_ms > 0 else 0.0,
             },
             "raw_c_abi_tets_per_s": m_local * args.steps / raw_elapsed,
             "energy": e_global,

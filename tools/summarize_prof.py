@@ -19,6 +19,7 @@ import csv
 import glob
 import json
 import os
+import sys
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +30,12 @@ def short(name: str) -> str:
         if key in name:
             return key + ("<true>" if "<true" in name else "<false>" if "<false" in name else "")
     return name[:60]
+
+
+def _traffic_digest():
+    sys.path.insert(0, ROOT)
+    from tssplat_amd import _build
+    return _build.traffic_digest()
 
 
 def main():
@@ -91,6 +98,9 @@ def main():
                 "read_bytes": tile["hbm_read_bytes_gfx950_corrected"],
                 "write_bytes": tile["hbm_write_bytes"],
                 "note": "FETCH_SIZE x 1024 x 2 (gfx950 wide-read correction) + WRITE_SIZE x 1024, separate --pmc passes",
+                # fingerprint of kernels.hip + plan.cpp + plan.h at the time of the measurement: bench.py drops the figure when
+                # the sources it runs have moved on (a static traffic.json goes stale silently)
+                "sources": _traffic_digest(),
             }
             json.dump(rec, open(tpath, "w"), indent=1, sort_keys=True)
             print("updated profiles/traffic.json:", rec[args.workload])

@@ -53,6 +53,17 @@ def _digest() -> str:
     return h.hexdigest()
 
 
+def traffic_digest() -> str:
+    """Fingerprint of the sources that decide how many bytes one evaluation moves (the tile kernel and the plan layout).
+    tools/summarize_prof.py stamps profiles/traffic.json with it when it condenses the rocprofv3 PMC passes; bench.py reports
+    ``roofline.traffic`` only while the stamp matches the sources it runs."""
+    h = hashlib.sha256()
+    for name in ("kernels.hip", "plan.cpp", "plan.h"):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_variant(name: str, extra_device_flags: list[str]) -> str:
     """Experiment helper: build libtssplat_amd_<name>.so with extra device flags (e.g. -DTSAMD_...).
     Select it at run time with TSSPLAT_AMD_LIB=<path>."""
