@@ -81,7 +81,7 @@ def _worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rest, tets, vo, to, x = _scene()
-        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, exchange="step")
         lo, hi = mod.vertex_range
         xl = torch.from_numpy(x[lo:hi]).requires_grad_(True)
         c1, c2 = mod.coeff_scheduler(0)
@@ -134,6 +134,7 @@ def test_two_ranks_match_unsharded_oracle():
 def test_single_process_is_identity():
     rest, tets, vo, to, x = _scene()
     mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
+    assert mod.exchange == "window"
     assert mod.world_size == 1 and mod.vertex_range == (0, rest.shape[0])
     xl = torch.from_numpy(x).requires_grad_(True)
     e = mod(xl, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff)
@@ -223,3 +224,103 @@ def test_windowed_energy_all_reduce_without_process_group():
     for i in range(10):
         red.push(torch.tensor(float(i)))
     assert np.array_equal(red.results().numpy(), np.arange(10, dtype=np.float32)) and red.collectives == 0
+
+
+def _scene_uneven(n_spheres, seed=3):
+    """Spheres of very different sizes (kuhn 1 .. 4: 6 .. 384 tets) so that the balanced cut is far from equal counts."""
+    rng = np.random.default_rng(seed)
+    ks = rng.integers(1, 5, size=n_spheres)
+    rest, tets, vo, to = [], [], [0], [0]
+    for k in ks:
+        v, t = scenes.kuhn_ball(int(k))
+        rest.append((v * rng.uniform(0.1, 0.3) + rng.uniform(-0.5, 0.5, 3)).astype(np.float32))
+        tets.append(t + vo[-1])
+        vo.append(vo[-1] + v.shape[0])
+        to.append(to[-1] + t.shape[0])
+    rest = np.concatenate(rest)
+    x = (rest + 0.03 * rng.standard_normal(rest.shape)).astype(np.float32)
+    return rest, np.concatenate(tets).astype(np.int32), np.array(vo), np.array(to), x
+
+
+def _worker8(rank, world, port, n_spheres, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rest, tets, vo, to, x = _scene_uneven(n_spheres)
+        # windowed exchange (the default): rank-local value per step, job-wide energies from reduced_energies()
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, window=4)
+        lo, hi = mod.vertex_range
+        xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
+        local, grads = [], None
+        for it in range(6):                                  # one full window + a partial one; order 2 throughout
+            c1, c2 = mod.coeff_scheduler(it)
+            e = mod(xl, it, c1 * (1 + it), c2)
+            xl.grad = None
+            e.backward()
+            local.append(float(e.detach()))
+            grads = xl.grad.numpy().copy()
+        reduced = mod.reduced_energies().numpy().copy()
+        # replicated-parameter mode on top of the per-step exchange
+        mod2 = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, exchange="step")
+        xf = torch.from_numpy(x).requires_grad_(True)
+        c1, c2 = mod2.coeff_scheduler(0)
+        ef = mod2.forward_replicated(xf, 0, c1, c2)
+        ef.backward()
+        out[rank] = (mod.sphere_range, (lo, hi), local, reduced, grads, float(ef), xf.grad.numpy().copy(),
+                     mod._reducer.collectives if mod._reducer is not None else 0)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_spheres", [13, 5])
+def test_eight_ranks_uneven_spheres_and_more_ranks_than_spheres(n_spheres):
+    """world_size 8 on CPU (gloo): 13 spheres of very different sizes, and 5 spheres for 8 ranks (three ranks own nothing,
+    contribute zero and still take part in every collective).  Windowed exchange: the per-step values are rank-local and
+    sum to the oracle's energy; reduced_energies() returns the job-wide energies of all six steps from two collectives;
+    replicated-parameter mode returns the full gradient on every rank."""
+    from oracle import tet_energy_oracle as O
+    world = 8
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker8, args=(world, _free_port(), n_spheres, out), nprocs=world, join=True)
+        rest, tets, vo, to, x = _scene_uneven(n_spheres)
+        cache = O.prepare(rest, tets)
+        E = [O.energy_and_grad(x, cache, _Flags.smooth_eng_coeff * (1 + it), _Flags.barrier_coeff, 2)[0] for it in range(6)]
+        E0, _, _, g0 = O.energy_and_grad(x, cache, _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2)
+        g5 = O.energy_and_grad(x, cache, _Flags.smooth_eng_coeff * 6, _Flags.barrier_coeff, 2)[3]
+        covered = np.zeros(rest.shape[0], dtype=bool)
+        owners = 0
+        for rank in range(world):
+            srange, (lo, hi), local, reduced, grads, ef, grad_full, ncoll = out[rank]
+            owners += srange[1] > srange[0]
+            assert ncoll == 2                                        # 6 steps, window 4: one full + one partial window
+            assert np.allclose(reduced, E, rtol=3e-6, atol=0)        # job-wide energies, every rank, in step order
+            assert grads.shape == (hi - lo, 3)
+            if hi > lo:                                              # (a rank without spheres owns no rows)
+                assert np.abs(grads - g5[lo:hi]).max() <= 1e-5 * np.abs(g5).max()   # rank-local gradient of the last step
+            assert abs(ef - E0) <= 3e-6 * abs(E0) and np.abs(grad_full - g0).max() <= 1e-5 * np.abs(g0).max()
+            assert not covered[lo:hi].any()
+            covered[lo:hi] = True
+        assert covered.all() and owners == min(world, n_spheres)
+        # the rank-local values of a step sum to the job-wide energy
+        for it in range(6):
+            assert abs(sum(out[r][2][it] for r in range(world)) - E[it]) <= 3e-6 * abs(E[it])
+
+
+def test_bench_spawns_eight_ranks_dry_run():
+    """`python bench.py --gpus 8 --dry-run`: the self-spawn route at the node's full width, more spheres than ranks and fewer
+    (5 spheres on 8 ranks: three ranks hold empty shards and still meet every collective)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for spheres in (19, 5):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run", "--spheres", str(spheres),
+                              "--steps", "3", "--warmup", "1"], capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["config"]["energy_allreduce_checked"] and rec["config"]["spheres_total"] == spheres
