@@ -247,6 +247,8 @@ def test_autograd_surface_and_cache(ext):
 
     sc = scenes.make_scene("kuhn8", 3)
     mod = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    mod._ext = None        # the Python Function and the operator functions' fused cache (the C++ node keeps its gradient in its
+                           # own context: test_cpp_autograd_nodes_equal_python_nodes)
     x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, 0.3)).cuda())
     c1, c2 = mod.coeff_scheduler(1200)
     assert abs(c1 / Flags.smooth_eng_coeff - 16.0) < 1e-9
@@ -688,3 +690,53 @@ def test_fused_train_loop_equals_eager(ext):
         loop.run(24)
     with pytest.raises(RuntimeError, match="exactly the parameter"):
         FusedEnergyAdamLoop(mod_f, xf, AdamUniform([xf, torch.nn.Parameter(x0.clone())]), n_iters=2)
+
+
+def test_cpp_autograd_nodes_equal_python_nodes(ext):
+    """``SmoothnessBarrierEnergy`` runs its autograd node in C++ (csrc/torch_autograd.cpp) when the in-tree
+    extension is there.  Same library calls as the Python Functions, so: bitwise-equal energies and gradients, eager and
+    replayed, with a second loss term, a CPU grad_output, the order switch and the stale-backward check."""
+    from tssplat_amd import _capi, scenes
+    from tssplat_amd.energies import SmoothnessBarrierEnergy
+
+    class Flags:
+        smooth_eng_coeff = 2e-4 / 6
+        barrier_coeff = 2e-4
+        increase_order_iter = 1000
+
+    assert _capi.autograd_ext() is not None, "the C++ autograd extension did not build / import on this box"
+    sc = scenes.make_scene("kuhn8", 6)
+    x0 = torch.from_numpy(scenes.deform(sc, 0.3)).cuda()
+    w = torch.randn_like(x0)
+    for graph in (False, True):
+        cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, graph=graph)
+        py = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, graph=graph)
+        py._ext = None                                              # force the Python Functions
+        xc, xp = torch.nn.Parameter(x0.clone()), torch.nn.Parameter(x0.clone())
+        for it in (0, 7, 600, 1001, 1500):
+            for mod, x in ((cpp, xc), (py, xp)):
+                x.grad = None
+                c1, c2 = mod.coeff_scheduler(it)
+                loss = (w * x).sum() * 1e-3 + 0.5 * mod(x, it, c1, c2)
+                loss.backward()
+                with torch.no_grad():
+                    x.add_(-1e-3 * x.grad.clamp(-0.05, 0.05))       # in place: the replay keeps its storage
+            e_c, e_p = float(cpp(xc, it, *cpp.coeff_scheduler(it)).detach()), float(py(xp, it, *py.coeff_scheduler(it)).detach())
+            assert np.isfinite(e_c) and e_c == e_p, (graph, it, e_c, e_p)
+            assert torch.equal(xc.grad, xp.grad), (graph, it)
+            assert torch.equal(xc, xp)
+        # grad_output on the CPU (a plain python-side constant): both routes move it to the device
+        xc.grad = None
+        cpp(xc, 3, 1e-4, 2e-4).backward(torch.tensor(2.0))
+        g2 = xc.grad.clone()
+        xc.grad = None
+        cpp(xc, 3, 1e-4, 2e-4).backward()
+        assert torch.allclose(g2, 2.0 * xc.grad, rtol=1e-6, atol=0)
+    # stale backward of a replayed evaluation: refused by the C++ node exactly like by the Python one
+    cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, graph=True)
+    x = torch.nn.Parameter(x0.clone())
+    e1 = cpp(x, 0, 1e-4, 2e-4)
+    e2 = cpp(x, 1, 1e-4, 2e-4)
+    with pytest.raises(RuntimeError, match="newer evaluation"):
+        e1.backward()
+    e2.backward()

@@ -236,3 +236,18 @@ def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, rebuild, bal
     E, Es, Eb, g = O.energy_and_grad(x, cache, 3e-5, 2e-4, 4, grad_output=0.7)
     E2, Es2, Eb2, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 4, grad_output=0.7)
     assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()
+
+
+def test_cpp_autograd_extension_builds_and_binds():
+    """csrc/torch_autograd.cpp: the in-tree host extension compiles against this torch, imports without a GPU and takes the
+    entry-point addresses of the loaded library; with the nodes unset it refuses to evaluate instead of crashing."""
+    import os
+    import torch
+    from tssplat_amd import _build
+    path = _build.build_torch_ext()
+    assert os.path.basename(path) == "_tsamd_autograd.so" and os.path.exists(path)
+    ext = _capi.autograd_ext()
+    assert ext is not None and {"energy_eval", "energy_replay", "set_entry_points"} <= set(dir(ext))
+    x = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match="float32 GPU tensor"):
+        ext.energy_eval(x, 0, 1.0, 1.0, 2)                    # CPU tensor: rejected before the library is called

@@ -61,3 +61,42 @@ run("same, coefficients from the schedule (change every step)", f_mod_graph_sche
 from tssplat_amd.energies import GraphedSmoothnessBarrier
 gr = GraphedSmoothnessBarrier(en, x)
 run("GraphedSmoothnessBarrier.step(it) (no autograd)", lambda i: gr.step(i % 900))
+
+# ---- the trainer's shape, `loss = a + energy(x, it, c1, c2); loss.backward()`, C++ nodes against Python nodes ----
+w = torch.randn_like(x.detach())
+def trainer_step(mod):
+    def f(i):
+        x.grad = None
+        it = i % 900
+        c1, c2 = mod.coeff_scheduler(it)
+        loss = (w * x).sum() + mod(x, it, c1, c2)
+        loss.backward()
+    return f
+for graph in (False, True):
+    m_cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=graph)
+    m_py = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=graph)
+    m_py._ext = None
+    tag = "graph=True " if graph else "eager      "
+    run(f"trainer-shaped step, {tag} C++ autograd node", trainer_step(m_cpp), N=4000)
+    run(f"trainer-shaped step, {tag} Python autograd Function", trainer_step(m_py), N=4000)
+def only_energy(mod):
+    def f(i):
+        x.grad = None
+        it = i % 900
+        c1, c2 = mod.coeff_scheduler(it)
+        mod(x, it, c1, c2).backward()
+    return f
+m_cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=True)
+run("energy(x).backward() alone, graph=True, C++ node", only_energy(m_cpp), N=4000)
+
+a_const = torch.tensor(0.37, device="cuda")
+def with_const(mod):
+    def f(i):
+        x.grad = None
+        it = i % 900
+        c1, c2 = mod.coeff_scheduler(it)
+        (a_const + mod(x, it, c1, c2)).backward()
+    return f
+for graph in (False, True):
+    m_cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=graph)
+    run(f"loss = a + energy(x, it, c1, c2); loss.backward()   graph={graph}, C++ node", with_const(m_cpp), N=4000)

@@ -114,5 +114,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+TORCH_EXT = os.path.join(_HERE, "_tsamd_autograd.so")
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    """Compile (if stale) tssplat_amd/_tsamd_autograd.so: the C++ autograd nodes of csrc/torch_autograd.cpp -- a plain host
+    extension (g++, torch headers, no device code; it reaches libtssplat_amd.so through the entry-point addresses the ctypes
+    loader hands it), in-tree like the library so that it travels to the GPU box with the snapshot."""
+    import sysconfig
+    src = os.path.join(CSRC, "torch_autograd.cpp")
+    stamp = os.path.join(_OBJ, "torch_ext_digest")
+    import torch
+    from torch.utils import cpp_extension as ce
+    h = hashlib.sha256(open(src, "rb").read())
+    h.update(torch.__version__.encode())
+    digest = h.hexdigest()
+    if not force and os.path.exists(TORCH_EXT) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return TORCH_EXT
+    os.makedirs(_OBJ, exist_ok=True)
+    cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
+    libdir = ce.library_paths()[0]
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_tsamd_autograd",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include", f"-I{sysconfig.get_paths()['include']}"]
+    cmd += [src, "-o", TORCH_EXT, f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", f"-Wl,-rpath,{libdir}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return TORCH_EXT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ext(force="--force" in sys.argv, verbose=True))

@@ -193,6 +193,40 @@ def load(build_if_missing: bool = True):
     return lib
 
 
+_autograd_ext = None
+
+
+def autograd_ext(build_if_missing: bool = True):
+    """The C++ autograd nodes (csrc/torch_autograd.cpp, tssplat_amd/_tsamd_autograd.so), wired to the entry points of the
+    library loaded above -- or ``None`` when the extension cannot be built or imported (the Python autograd Functions of
+    tssplat_amd.energies are then used: same results, 2-3x the host time per step).  TSSPLAT_AMD_PY_AUTOGRAD=1 forces that
+    fallback."""
+    global _autograd_ext
+    if _autograd_ext is not None:
+        return _autograd_ext or None
+    if os.environ.get("TSSPLAT_AMD_PY_AUTOGRAD") == "1":
+        _autograd_ext = False
+        return None
+    lib = load()
+    try:
+        if build_if_missing:
+            try:
+                _build.build_torch_ext()
+            except Exception:
+                if not os.path.exists(_build.TORCH_EXT):
+                    raise
+        import importlib
+        ext = importlib.import_module("tssplat_amd._tsamd_autograd")
+        addr = lambda fn: C.cast(fn, C.c_void_p).value
+        ext.set_entry_points(addr(lib.tsamd_graph_launch), addr(lib.tsamd_forward_backward), addr(lib.tsamd_last_error))
+        _autograd_ext = ext
+    except Exception as exc:                           # noqa: BLE001
+        import warnings
+        warnings.warn(f"tssplat_amd: C++ autograd extension unavailable ({exc}); using the Python autograd Functions")
+        _autograd_ext = False
+    return _autograd_ext or None
+
+
 def check(rc: int) -> None:
     if rc != 0:
         raise TsamdError(rc, load().tsamd_last_error().decode("utf-8", "replace"))

@@ -57,7 +57,24 @@ class GraphedSmoothnessBarrier:
         self.grad = torch.zeros_like(x.detach())
         self._scale = torch.full((1,), float(grad_scale), dtype=torch.float32, device=dev)
         self._graphs: dict[int, C.c_void_p] = {}
-        self.ticket = 0            # evaluations so far (GraphReplayFunc: a backward must belong to the latest one)
+        # evaluations so far (a backward must belong to the latest one): a one-element CPU tensor so that the C++ autograd node
+        # (csrc/torch_autograd.cpp) and GraphReplayFunc count on the same cell
+        self.ticket_tensor = torch.zeros(1, dtype=torch.int64)
+
+    @property
+    def ticket(self) -> int:
+        return int(self.ticket_tensor[0])
+
+    @ticket.setter
+    def ticket(self, value: int) -> None:
+        self.ticket_tensor[0] = int(value)
+
+    def graph_address(self, order: int) -> int:
+        """Address of the library graph for ``order`` (created on first use) -- what the C++ autograd node launches."""
+        g = self._graphs.get(order)
+        if g is None:
+            g = self._graphs[order] = self._create(order)
+        return int(g.value)
 
     def _create(self, order: int) -> C.c_void_p:
         g = C.c_void_p()

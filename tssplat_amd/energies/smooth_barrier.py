@@ -60,6 +60,7 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
         f_flat = np.asarray(tet_f).flatten().astype(np.int32)        # smooth_barrier.py:39
         self.tet_sp = tet_spheres_ext.TetSpheres(v_flat, f_flat, **tet_spheres_kwargs)
         self.FLAGS = FLAGS
+        self._ext = False                                     # C++ autograd extension: looked up on the first differentiable call
         self.smooth_eng_func = SmoothnessBarrierFunc          # (the reference instantiates the Function, smooth_barrier.py:45; torch deprecates that)
 
     def coeff_scheduler(self, it):
@@ -75,10 +76,23 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
             # logging / validation under torch.no_grad(): energy only -- no fused gradient pass, and a gradient kept for a
             # pending backward() of an earlier evaluation stays where it is
             return tet_spheres_ext.forward(x, self.tet_sp, c1, c2, order, fuse=False)
+        # The autograd node is a C++ torch::autograd::Function when the in-tree extension is there (csrc/torch_autograd.cpp: one
+        # call into the C ABI per evaluation, no Python frame in forward or backward); the Python Functions of this package
+        # are the fallback and the reference-spelled surface.
+        ext = self._ext
+        if ext is False:
+            from .. import _capi
+            ext = self._ext = _capi.autograd_ext()
         if self.graph and x.requires_grad:
             from .graphed import GraphedSmoothnessBarrier, GraphReplayFunc
             gr = self._graphed
             if gr is None or gr.x.data_ptr() != x.data_ptr() or gr.x.shape != x.shape:
                 gr = self._graphed = GraphedSmoothnessBarrier(self, x.detach())   # (re)capture for this storage
+            if ext is not None:
+                return ext.energy_replay(x, gr.graph_address(order), c1, c2, gr.energy, gr.grad, gr.ticket_tensor)
             return GraphReplayFunc.apply(x, gr, c1, c2, order)
+        if (ext is not None and not tet_spheres_ext.cpu_energy_mode() and x.is_cuda and x.dtype == torch.float32
+                and x.numel() == self.tet_sp.n3 and x.device == self.tet_sp.device):
+            self.tet_sp._cache = None      # (a fused result kept by the operator functions belongs to an older evaluation now)
+            return ext.energy_eval(x, int(self.tet_sp._handle().value), c1, c2, order)
         return SmoothnessBarrierFunc.apply(x, self.tet_sp, c1, c2, order)

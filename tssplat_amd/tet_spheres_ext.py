@@ -217,6 +217,11 @@ def _cache_key(x: torch.Tensor, c1: float, c2: float, order: int):
     return (x.data_ptr(), x._version, x.shape, float(c1), float(c2), int(order))
 
 
+def cpu_energy_mode() -> bool:
+    """True while ``forward`` returns the energy as a CPU tensor, the reference's convention (see the module docstring)."""
+    return CPU_ENERGY
+
+
 def forward(input: torch.Tensor, tet_sph: TetSpheres, c1: float, c2: float, order: int, *,
             fuse: bool | None = None) -> torch.Tensor:
     """Energy ``c1 * 1/2 |L G x|^2 + c2 * sum_e max(-det F_e, 0)^order`` (tet_spheres_cuda.cu:118-195).
