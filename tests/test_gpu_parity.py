@@ -198,6 +198,21 @@ def test_cone_hub_vertex(ext):
     _assert_parity(ext, ts, sc.rest, sc.tets, x, 1e-4, 2e-4, 2, label="cone x5")
 
 
+def test_config1_literal_fixture_s1_cone(ext):
+    """BASELINE.json config 1 names mesh_data/s.1.obj: the reference's template sphere (tests/golden/s1_sphere.npz, verbatim)
+    coned to its centroid -- 2 996 tets around ONE vertex of valence 2 996 -- alone and replicated, order
+    2 and 4, mildly and strongly deformed."""
+    from tssplat_amd import scenes
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s1_sphere.npz"))
+    cv, ct = scenes.cone_sphere(g["vertices"].astype(np.float64), g["faces"])
+    assert ct.shape[0] == 2996 and np.bincount(ct.reshape(-1)).max() == 2996
+    for n_spheres, sigma, order in ((1, 0.02, 2), (1, 0.3, 4), (6, 0.2, 2)):
+        sc = scenes.replicate_spheres(cv, ct, n_spheres)            # radii U(0.05, 0.30), like every scene of SURVEY 8(d)
+        ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+        x = scenes.deform(sc, sigma)
+        _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / n_spheres, 2e-4, order, label=f"s1_cone x{n_spheres} sigma {sigma} order {order}")
+
+
 def test_known_answers_on_gpu(ext):
     from tssplat_amd import scenes
     sc = scenes.make_scene("kuhn8", 2)

@@ -3,6 +3,8 @@
 regulariser -> backward -> AdamUniform.  GPU tests; the CPU test checks the modules refuse to run without a GPU."""
 import types
 
+import os
+
 import numpy as np
 import pytest
 
@@ -96,3 +98,61 @@ def test_silhouette_fit_converges():
     d = np.linalg.det(np.stack([x[t[:, 1]] - x[t[:, 0]], x[t[:, 2]] - x[t[:, 0]], x[t[:, 3]] - x[t[:, 0]]], axis=1))
     d0 = np.linalg.det(np.stack([sc.rest[t[:, 1]] - sc.rest[t[:, 0]], sc.rest[t[:, 2]] - sc.rest[t[:, 0]], sc.rest[t[:, 3]] - sc.rest[t[:, 0]]], axis=1))
     assert (np.sign(d) == np.sign(d0)).mean() > 0.99
+
+
+def test_dataset_cameras_follow_the_reference_script():
+    """scenes.dataset_mvps = data/render_dataset.py:15-57,96-148: golden-ratio spiral at radius 4, its look_at (eye on -z of the
+    view frame, right = lookat x up) and its perspective (flipped y row, fov 39.3077, near 0.001, far 10)."""
+    m = scenes.dataset_mvps(120).astype(np.float64)
+    assert m.shape == (120, 4, 4)
+    o = m @ np.array([0.0, 0.0, 0.0, 1.0])                        # the origin sits in the image centre, 4 in front of every eye
+    assert np.abs(o[:, :2]).max() < 1e-6 and np.allclose(o[:, 3], 4.0, atol=1e-5)
+    t = np.tan(np.radians(39.3077) / 2)
+    # a point one unit "up" in the first view's frame lands at y_ndc = -1 / (t * w) (the script flips y)
+    golden = (1 + 5 ** 0.5) / 2
+    i = 7
+    theta, phi = 2 * np.pi * i / golden, np.arccos(1 - 2 * i / 120)
+    eye = 4 * np.array([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)])
+    look = -eye / 4
+    right = np.cross(look, [0, 0, 1.0])
+    right /= np.linalg.norm(right)
+    up = np.cross(right, look)
+    c = m[i] @ np.append(0.5 * up, 1.0)
+    assert abs(c[0] / c[3]) < 1e-6 and np.isclose(c[1] / c[3], -0.5 / (t * 4.0), atol=1e-6)
+    c = m[i] @ np.append(0.5 * right, 1.0)
+    assert np.isclose(c[0] / c[3], 0.5 / (t * 4.0), atol=1e-6) and abs(c[1] / c[3]) < 1e-6
+
+
+def test_mesh_goldens_from_the_reference():
+    """tests/golden/make_mesh_goldens.py: the reference's template sphere verbatim (closed, 1 500 / 2 996) and its one object."""
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s1 = np.load(os.path.join(g, "s1_sphere.npz"))
+    v, f = s1["vertices"], s1["faces"]
+    assert v.shape == (1500, 3) and f.shape == (2996, 3) and v.dtype == np.float32 and f.dtype == np.int32
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all() and len(cnt) == 3 * 2996 // 2           # closed 2-manifold: V - E + F = 2
+    assert 1500 - len(cnt) + 2996 == 2
+    assert abs(np.linalg.norm(v, axis=1).mean() - 1.0) < 0.05       # a unit sphere
+    m = np.load(os.path.join(g, "mario_mesh.npz"))
+    assert np.linalg.norm(m["vertices"], axis=1).max() <= 1.0 + 1e-6 and m["faces"].max() < m["vertices"].shape[0]
+    cv, ct = scenes.cone_sphere(v, f)                               # BASELINE config 1's literal fixture: one hub of valence 2 996
+    assert ct.shape == (2996, 4) and np.bincount(ct.reshape(-1)).max() == 2996
+
+
+@pytest.mark.gpu
+def test_config5_fit_to_the_reference_object():
+    """BASELINE config 5 with the reference's own object: tet-spheres placed in the visual hull of silhouettes
+    of mesh_data/mario_example/model.obj (golden: mario_mesh.npz) and fitted with the reference's loop and schedule
+    (tools/train_object.py): the full 120 views x 512^2 x 1 500 iterations of config/gso.yaml -- about five seconds on an MI355X
+    (profiles/r04_train_mario.json: IoU 0.971, 2.7 ms per iteration)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_object", os.path.join(root, "tools", "train_object.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rec = mod.run(n_spheres=20, k=8, views=120, res=512, iters=1500, stages=False)
+    assert rec["spheres"]["placed"] >= 12
+    assert rec["silhouette_iou_at_start"] < 0.7 < 0.9 <= rec["silhouette_iou"], rec["silhouette_iou"]
+    assert rec["inverted_tets"] <= 0.01 * rec["tets"]
+    assert rec["img_loss_first_last"][1] < 0.15 * rec["img_loss_first_last"][0]

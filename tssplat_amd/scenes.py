@@ -318,6 +318,38 @@ def orbit_mvps(n_views: int, distance: float = 3.0, fov_deg: float = 40.0, near:
     return np.stack(out).astype(np.float32)
 
 
+def dataset_mvps(n_views: int, radius: float = 4.0, fov_deg: float = 39.3077, near: float = 0.001, far: float = 10.0) -> np.ndarray:
+    """The camera set of the reference's image data (/root/reference/data/render_dataset.py:15-57, :96-148): ``n_views`` eyes on a
+    golden-ratio spiral over the sphere of ``radius`` around the origin, looking at the origin (up = z, or y when the view
+    direction comes within 22.5 degrees of z), projection = the script's ``perspective()`` (note its flipped y row).  Returns
+    ``projection @ view`` per view, float32 ``[n, 4, 4]`` -- the ``mvp`` batch trainer.py hands to ``MeshRasterizer.forward``."""
+    golden = (1 + 5 ** 0.5) / 2
+    i = np.arange(n_views)
+    theta = 2 * np.pi * i / golden
+    phi = np.arccos(1 - 2 * i / n_views)
+    eyes = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], axis=1) * radius
+    t = np.tan(np.radians(fov_deg) * 0.5)
+    proj = np.zeros((4, 4))
+    proj[0, 0], proj[1, 1] = 1 / t, -1 / t
+    proj[2, 2], proj[3, 2], proj[2, 3] = -(far + near) / (far - near), -1, -(2 * far * near) / (far - near)
+    out = []
+    for eye in eyes:
+        d = eye / np.linalg.norm(eye)
+        up = np.array([0.0, 0.0, 1.0])
+        if abs(np.dot(up, d)) > np.cos(np.pi / 8):
+            up = np.array([0.0, 1.0, 0.0])
+        look = -d
+        right = np.cross(look, up)
+        right /= np.linalg.norm(right)
+        up = np.cross(right, look)
+        up /= np.linalg.norm(up)
+        view = np.eye(4)
+        view[0, :3], view[1, :3], view[2, :3] = right, up, -look
+        view[0, 3], view[1, 3], view[2, 3] = -np.dot(right, eye), -np.dot(up, eye), np.dot(look, eye)
+        out.append(proj @ view)
+    return np.stack(out).astype(np.float32)
+
+
 def transform_pos(mvp: np.ndarray, pos: np.ndarray) -> np.ndarray:
     """``[v, 1] @ mvp^T`` per view, float32 (mesh_rasterizer.py:57-78, non-ortho branch)."""
     posw = np.concatenate([np.asarray(pos, dtype=np.float32), np.ones((pos.shape[0], 1), dtype=np.float32)], axis=1)
