@@ -86,7 +86,7 @@ typedef struct tsamd_plan_info {
     int64_t device_bytes;        /* bytes of plan data resident in HBM                              */
     int32_t max_slots, max_tile_vertices, block_threads, lds_bytes;
     int32_t slots_per_thread;
-    int32_t n_planes;            /* dword planes per tile slot: 13; 22 with an explicit element operator; 4 with rebuild_dminv */
+    int32_t n_planes;            /* dword planes per tile slot: 13; 22 with an explicit element operator (18 when it is symmetric); 4 with rebuild_dminv */
 } tsamd_plan_info;
 
 /* One tile of the plan, as host pointers into the handle (valid until tsamd_destroy).
@@ -126,7 +126,8 @@ int tsamd_create_from_veg(const char *path, const tsamd_options *options, tsamd_
  * row-scaled scale=1 variant): m x m CSR over tets, double values (rounded to fp32 like the reference's
  * matrix values, tet_spheres.cpp:43-45), 0-based.  Entries must lie on the diagonal or on a face adjacency of
  * the mesh (duplicates are summed); anything else is TSAMD_ERR_INVALID_ARGUMENT.  L need not be symmetric:
- * the gradient applies L^T explicitly.  Cost: 9 more fp32 planes per tile slot (88 instead of 52 bytes).
+ * the gradient applies L^T explicitly.  Cost: 9 more fp32 planes per tile slot (88 instead of 52 bytes); 5 (72 bytes) when
+ * the operator is symmetric after the rounding to fp32 -- its weights are then stored once and serve both passes.
  */
 int tsamd_create_with_operator(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
                                const int64_t *op_rowptr, const int32_t *op_col, const double *op_val,

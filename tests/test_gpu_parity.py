@@ -478,9 +478,10 @@ def test_explicit_operator_parity(ext, kind, S, kw):
     cols = nbr.ravel()
     ok = cols >= 0
     Lr = (sp.diags(rng.uniform(1.0, 5.0, m)) + sp.csr_matrix((rng.uniform(-2.0, -0.2, ok.sum()), (rows[ok], cols[ok])), shape=(m, m))).tocsr()
-    for name, L in (("scaled", O.element_laplacian_scaled(nbr)), ("random", Lr), ("uniform", O.element_laplacian(nbr))):
+    Ls = (sp.diags(Lr.diagonal()) + 0.5 * ((Lr - sp.diags(Lr.diagonal())) + (Lr - sp.diags(Lr.diagonal())).T)).tocsr()   # symmetric, random weights
+    for name, L in (("scaled", O.element_laplacian_scaled(nbr)), ("random", Lr), ("symmetric", Ls), ("uniform", O.element_laplacian(nbr))):
         ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), operator=L, **kw)
-        assert ts.plan_info()["n_planes"] == 22
+        assert ts.plan_info()["n_planes"] == (18 if name in ("uniform", "symmetric") else 22)    # a symmetric operator stores its weights once
         for sigma, order in ((0.02, 2), (0.3, 4)):
             x = scenes.deform(sc, sigma)
             _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / S, 2e-4, order, go=0.5, L=L,

@@ -147,7 +147,8 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         else:                                 # explicit element operator: L[e,e], L[e,n_k], L[n_k,e]
             wd = pl[13].view(np.float32).astype(np.float64)
             wr = pl[14:18].view(np.float32).astype(np.float64).T
-            wc = pl[18:22].view(np.float32).astype(np.float64).T
+            # (a symmetric operator stores its weights once: 18 planes, pass 3 applies the row weights -- plan.h)
+            wc = pl[18:22].view(np.float32).astype(np.float64).T if pl.shape[0] == 22 else wr
             assert np.all(wr[missing] == 0) and np.all(wc[missing] == 0)
         H = wd[:, None] * F.reshape(sp, 9) + (wr[:, :, None] * Fz[nb]).sum(axis=1)
         H[~owned] = 0.0

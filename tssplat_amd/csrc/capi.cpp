@@ -215,7 +215,8 @@ tsamd::EvalArgs eval_args(tsamd_handle *h, const float *x, const float *grad_out
     a.block_threads = h->plan.block_threads;
     a.lds_bytes = h->plan.lds_bytes;
     a.vert_stride = h->plan.vert_stride;
-    a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted;
+    a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted || h->plan.n_planes == tsamd::kPlanesWeightedSym;
+    a.n_planes = h->plan.n_planes;
     a.rebuild = h->plan.n_planes == tsamd::kPlanesRebuild;
     a.dbg = h->dbg;
     a.clk = h->d_clk;

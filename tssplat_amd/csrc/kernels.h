@@ -19,7 +19,8 @@ struct EvalArgs {
     int32_t block_threads, lds_bytes;
     int32_t vert_stride = 0;      // gvid entries per tile (Plan::vert_stride)
     bool rebuild = false;         // the plan keeps rest positions instead of the Dm^-1 planes (kPlanesRebuild)
-    bool weighted = false;        // the plan carries an explicit element operator (22 planes per slot)
+    bool weighted = false;        // the plan carries an explicit element operator (22 planes per slot; 18 when it is symmetric)
+    int32_t n_planes = 13;        // dword planes per slot of this plan (where a tile's incidence list starts)
     int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
     long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
     // per evaluation

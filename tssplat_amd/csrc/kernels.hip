@@ -285,6 +285,7 @@ struct KernelArgs {
     int n_tiles;
     int tiles_per_xcd;
     int vert_stride;   // gvid entries per tile: tile t's vertex ids start at t * vert_stride (= its descriptor's vert_off)
+    int n_planes;      // dword planes per slot (explicit-operator plans: 22, or 18 for a symmetric operator -- plan.h)
     int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
     long long *clk;  // ablation builds: 16 shader-clock stamps per wave (up to 16 waves) per tile
 };
@@ -396,7 +397,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // of pass 1 -- 4.5 k cycles, every wave at once -- came after the last byte.)
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01, q_nb23;
     VF dm[9];
-    constexpr int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? kPlanesWeighted : kPlanes);
+    const int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? a.n_planes : kPlanes);   // (a compile-time constant unless WEIGHTED)
     // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
     unsigned char *rs = xs + 16 * VP;
     const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
@@ -446,7 +447,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     VF dm[9];
-    constexpr int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? kPlanesWeighted : kPlanes);
+    const int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? a.n_planes : kPlanes);   // (a compile-time constant unless WEIGHTED)
     // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
     unsigned char *rs = xs + 16 * VP;
     const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
@@ -502,9 +503,19 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     const bool factored = k_c1 != 0.f && __builtin_fabsf(ratio) <= 0x1p+40f;   // (false for inf and NaN as well)
     const float s_pen = factored ? ratio : k_c2, out_scale = factored ? k_c1 : 1.f, q_scale = factored ? 1.f : k_c1;
     // byte address of each own record's ninth entry (see load_slot), once per slot instead of once per access
-    uint32_t t_own[SPT];
+    uint32_t t_own_reg[SPT];
 #pragma unroll
-    for (int p = 0; p < SPT; ++p) t_own[p] = own_token_addr(uint32_t(p * nq + tid));
+    for (int p = 0; p < SPT; ++p) t_own_reg[p] = own_token_addr(uint32_t(p * nq + tid));
+    // The explicit-operator build has its ten weight registers on top of everything else: there the address is recomputed at
+    // each of its five uses (from an opaque copy of the lane id, or the compiler keeps the result in a register all the same)
+    // -- with it the vertex offsets stay in registers for pass 3 like in the built-in kernel, without a spill.
+    auto t_own_at = [&](int p) -> uint32_t {
+        if (!WEIGHTED) return t_own_reg[p];
+        uint32_t t = uint32_t(tid);
+        asm volatile("" : "+v"(t));
+        return own_token_addr(uint32_t(p * nq) + t);
+    };
+#define t_own(p) t_own_at(p)
 
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
     float scal[SPT];  // (c2 / c1) * d(penalty)/d(det F), 0 unless owned and inverted
@@ -542,7 +553,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 e_b += pen;
                 scal[p] = s_pen * dpen;
             }
-            store_slot(smem, t_own[p], F);
+            store_slot(smem, t_own(p), F);
             SLOT_FENCE();
 #ifdef TSAMD_STAMPS
             if (p == 0) STAMP(12);   // planes arrived, F of the first slot stored
@@ -580,16 +591,16 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
             if (n01 & kOwnedBit) {
                 uint32_t nb[4];
                 neighbours(n01, n23, nb);
-                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = t_own[p];
+                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = t_own(p);
                 Mat9 h;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    h = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
+                    h = operator_gather(smem, load_slot(smem, t_own(p)), wd[p], w4, nb);
                 } else {
 #ifdef TSAMD_EXP_PARTNER
-                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own[p]), nb, mat9_of(Fk[1 - p]));
+                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own(p)), nb, mat9_of(Fk[1 - p]));
 #else
-                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own[p]), nb);
+                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own(p)), nb);
 #endif
                 }
                 v2f sq = h.p01 * h.p01;
@@ -658,8 +669,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         if (active) {
             // (Dm^-1, needed again by pass 3, stays in registers)
 #pragma unroll
-            for (int p = 0; p < SPT; ++p) store_slot(smem, t_own[p], H[p]);   // (zeros on halo and padding slots)
-            if (WEIGHTED) {   // pass 3 applies L^T: the column weights L[n_k, e]
+            for (int p = 0; p < SPT; ++p) store_slot(smem, t_own(p), H[p]);   // (zeros on halo and padding slots)
+            if (WEIGHTED && a.n_planes == kPlanesWeighted) {   // pass 3 applies L^T: the column weights L[n_k, e] (a symmetric
+                                                               // operator has none: the row weights serve both passes)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
             }
@@ -682,13 +694,13 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 asm volatile("" : "+v"(n01), "+v"(n23));
                 uint32_t nb[4];
                 neighbours(n01, n23, nb);
-                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = t_own[p];
+                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = t_own(p);
 #ifdef TSAMD_DUMMY_LDS   // experiments: marginal cost of LDS reads (conflict-free b128 reads of the own record, results unused)
                 {
                     v4f dummy;
 #pragma unroll
                     for (int j = 0; j < TSAMD_DUMMY_LDS; ++j)
-                        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(dummy) : "v"(t_own[p] & ~15u));
+                        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(dummy) : "v"(t_own(p) & ~15u));
                     asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(dummy));
                 }
 #endif
@@ -696,12 +708,12 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 Mat9 q;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    q = operator_gather(smem, load_slot(smem, t_own[p]), wd[p], w4, nb);
+                    q = operator_gather(smem, load_slot(smem, t_own(p)), wd[p], w4, nb);
                 } else {
 #ifdef TSAMD_EXP_PARTNER
-                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb, mat9_of(H[1 - p]));
+                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own(p)), nb, mat9_of(H[1 - p]));
 #else
-                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own[p]), nb);
+                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own(p)), nb);
 #endif
                 }
 #ifdef TSAMD_DUMMY_VALU  // experiments: marginal cost of VALU instructions (independent FMAs on four accumulators)
@@ -725,6 +737,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                     // in the middle of pass 3.  Keeping them costs one VGPR (78) and no scratch: tile kernel 0.4633 -> 0.4324 ms
                     // at sigma = 0.02, 0.4793 -> 0.4330 ms at sigma = 0.3; profiles/r03_experiments.md.  The explicit-operator
                     // build has no register left for them -- it would spill two -- and still re-fetches.)
+#ifdef TSAMD_WEIGHTED_REFETCH
                     if (WEIGHTED) {   // (the address is rebuilt from an opaque copy of the lane id, or it would be kept in two VGPRs
                                       // from the stream phase on)
                         int lt2 = lt;
@@ -732,6 +745,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                         q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
                         q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt2);
                     }
+#endif
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
                     slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
@@ -780,7 +794,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         if (active) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
-                const uint32_t r = t_own[p] & ~15u;
+                const uint32_t r = t_own(p) & ~15u;
                 const float *d = D[p];
                 *lds_at<v4f>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
                 *lds_at<v4f>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
@@ -858,6 +872,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamp 9 - stamp 8 = what s_endpgm waits for: the result stores' acknowledgement
 #endif
     STAMP(9);
+#undef t_own
 }
 
 
@@ -1232,6 +1247,7 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
         k.n_tiles = int(e.n_tiles);
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.vert_stride = e.vert_stride;
+        k.n_planes = e.n_planes;
         k.dbg = e.dbg;
         k.clk = e.clk;
         if (e.block_threads > kTileThreads) return hipErrorInvalidConfiguration;

@@ -426,6 +426,21 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
         for (int64_t e = 0; e < m; ++e) P.op_diag[size_t(e)] = float(dg[size_t(e)]);   // double -> fp32, as the
         for (int64_t i = 0; i < 4 * m; ++i) P.op_w[size_t(i)] = float(w[size_t(i)]);   // reference rounds its matrices
+        // symmetric in fp32?  then the column weights are the row weights and their four planes are not stored (kPlanesWeightedSym)
+        bool symmetric = true;
+        for (int64_t e = 0; e < m && symmetric; ++e)
+            for (int k = 0; k < 4; ++k) {
+                const int32_t q = P.nbr[4 * size_t(e) + k];
+                if (q < 0) continue;
+                float back = 0.f;
+                for (int f = 0; f < 4; ++f)
+                    if (P.nbr[4 * size_t(q) + f] == e) back = P.op_w[4 * size_t(q) + f];
+                if (back != P.op_w[4 * size_t(e) + k]) {
+                    symmetric = false;
+                    break;
+                }
+            }
+        if (symmetric) P.n_planes = kPlanesWeightedSym;
     }
     const bool weighted = op != nullptr;
     const bool rebuild = lim.rebuild;
@@ -818,7 +833,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 if (P.nbr[4 * size_t(q) + f] == el) wc = P.op_w[4 * size_t(q) + f];
                         }
                         putf(14 + k, wr);
-                        putf(18 + k, wc);
+                        if (n_planes == kPlanesWeighted) putf(18 + k, wc);
                     }
                 }
                 pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
@@ -892,6 +907,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 p3[sl] = record_token(chosen[li][2]) | (record_token(chosen[li][3]) << 16);
                                 if (weighted)
                                     for (int base_plane : {14, 18}) {
+                                        if (base_plane + 4 > n_planes) continue;   // (symmetric operator: no column-weight planes)
                                         uint32_t old[4];
                                         for (int k = 0; k < 4; ++k) old[k] = pl[size_t(base_plane + k) * size_t(d.s_pad) + sl];
                                         for (int k = 0; k < 4; ++k)

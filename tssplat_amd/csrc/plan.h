@@ -72,6 +72,10 @@ constexpr int kTileThreads = 768;
 // (0 where a face has no neighbour and the token points at the slot itself).  Without an operator the kernels use the uniform face-adjacency
 // umbrella (diagonal = number of face neighbours, off-diagonals = -1) and these planes do not exist.
 constexpr int kPlanesWeighted = 22;
+// A SYMMETRIC operator (L[e, n_k] == L[n_k, e] for every face, after the rounding to fp32 -- e.g. the uniform umbrella passed as
+// data, or any weighted graph Laplacian) needs the weights once: planes [13] and [14..17] only, 72 instead of 88 bytes per slot;
+// pass 3 applies L^T = L with the row weights it already holds.
+constexpr int kPlanesWeightedSym = 18;
 // Plans built with rebuild_dminv carry only the four index planes (16 bytes per slot instead of 52) and, behind the
 // incidence offsets (16-byte aligned), one float4 per tile vertex with its REST position; the kernels stage those next
 // to the current positions and rebuild Dm^-1 = cofactor^T / det per slot in fp32 registers.  This is NOT bit-identical
