@@ -756,3 +756,46 @@ def test_cpp_autograd_nodes_equal_python_nodes(ext):
     with pytest.raises(RuntimeError, match="newer evaluation"):
         e1.backward()
     e2.backward()
+
+
+def test_graph_replay_back_to_back_without_sync(ext):
+    """``tsamd_graph_launch`` updates the coefficient arguments of the graph's kernel nodes
+    (hipGraphExecKernelNodeSetParams) while earlier launches of the same exec may still be queued -- the real training
+    path never synchronises between steps.  400 launches issued back to back on a scene whose kernels take several times
+    longer than the host needs per launch (the queue is dozens of launches deep), a different (c1, c2) every launch, the order
+    switch in the middle; every launch's energy and a gradient checksum are copied out ON THE STREAM and compared, after one
+    final sync, with evaluations done one at a time.  A runtime that patched the arguments in place would hand early launches
+    the coefficients of later ones."""
+    from tssplat_amd import scenes
+    from tssplat_amd.energies import SmoothnessBarrierEnergy, GraphedSmoothnessBarrier
+
+    class Flags:
+        smooth_eng_coeff = 2e-4 / 24
+        barrier_coeff = 2e-4
+        increase_order_iter = 1000
+
+    sc = scenes.make_scene("kuhn19", 24)                         # ~1 M tets: ~25 us of kernels per launch
+    mod = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    x = torch.from_numpy(scenes.deform(sc, 0.1)).cuda()
+    graphed = GraphedSmoothnessBarrier(mod, x)
+    iters = [3 * i for i in range(400)]                          # 0 .. 1197: crosses it = 1000 (order 2 -> 4), coefficients change every step
+    e_out = torch.zeros(len(iters), device="cuda")
+    g_out = torch.zeros(len(iters), device="cuda")
+    w = torch.randn_like(x)
+    graphed.step(0)
+    torch.cuda.synchronize()
+    for k, it in enumerate(iters):                               # no synchronisation inside this loop
+        e, g = graphed.step(it)
+        e_out[k].copy_(e)
+        g_out[k].copy_((g * w).sum())
+    torch.cuda.synchronize()
+    e_ref = torch.zeros_like(e_out)
+    g_ref = torch.zeros_like(g_out)
+    for k, it in enumerate(iters):
+        e, g = graphed.step(it)
+        torch.cuda.synchronize()                                 # one at a time
+        e_ref[k] = e
+        g_ref[k] = (g * w).sum()
+    assert torch.equal(e_out, e_ref), int((e_out != e_ref).sum())
+    assert torch.equal(g_out, g_ref), int((g_out != g_ref).sum())
+    assert len(set(e_ref.tolist())) > 300                        # the schedule really moved the result from launch to launch

@@ -503,3 +503,16 @@ def test_interpolate_bounds_on_foreign_rast():
     empty = torch.zeros((0, 3), dtype=torch.int32, device="cuda")
     out0, _ = dr.interpolate(attr.detach(), rast.detach(), empty)
     assert float(out0.abs().max()) == 0.0
+
+
+def test_dropped_triangle_counter():
+    """dr.count_dropped_triangles (TSSPLAT_AMD_DR_CHECK=1 makes dr.rasterize warn with it): the (view, triangle) pairs this slice
+    drops whole where nvdiffrast would clip -- a vertex at w <= 0, not finite, or beyond the +-16384-pixel guard band."""
+    import torch
+    import tssplat_amd.dr as dr
+    pos = torch.tensor([[[0, 0, 0, 1.0], [1, 0, 0, 1], [0, 1, 0, -1.0], [0.5, 0.5, 0, 1], [float("nan"), 0, 0, 1], [4000.0, 0, 0, 1]],
+                        [[0, 0, 0, 1.0], [1, 0, 0, 1], [0, 1, 0, 1.0], [0.5, 0.5, 0, 1], [0.0, 0, 0, 1], [0.0, 0, 0, 1]]])
+    tri = torch.tensor([[0, 1, 2], [0, 1, 3], [0, 1, 4], [0, 1, 5]], dtype=torch.int32)
+    # view 0: w <= 0, fine, NaN, 4000 * 0.5 * 64 = 128 000 px -> three dropped; view 1: nothing dropped
+    assert dr.count_dropped_triangles(pos, tri, 64, 64) == 3
+    assert dr.count_dropped_triangles(pos[1:], tri, 64, 64) == 0

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 import weakref
 
+import os
+
 import torch
 
 from . import _capi
@@ -50,6 +52,34 @@ def _check_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError(f"tssplat_amd.dr: {name} must be float32")
     return t.contiguous()
+
+
+# TSSPLAT_AMD_DR_CHECK=1: count, on every rasterize call, the triangles this slice DROPS where nvdiffrast would clip them -- a
+# vertex at w <= 0 (or not finite) or outside the +-16384-pixel guard band -- and warn.  A device read per call: a debugging
+# aid for scenes that may reach the eye plane, off by default (objects inside the frustum, the reference's case, lose nothing).
+_CHECK_DROPPED = os.environ.get("TSSPLAT_AMD_DR_CHECK", "0") == "1"
+
+
+def count_dropped_triangles(pos: torch.Tensor, tri: torch.Tensor, height: int, width: int) -> int:
+    """(view, triangle) pairs that ``rasterize`` drops whole instead of clipping (see the module docstring)."""
+    with torch.no_grad():
+        w = pos[..., 3]
+        ok = torch.isfinite(pos).all(dim=-1) & (w > 0)
+        ws = torch.where(ok, w, torch.ones_like(w))
+        sx = (pos[..., 0] / ws * 0.5 + 0.5) * width
+        sy = (pos[..., 1] / ws * 0.5 + 0.5) * height
+        ok &= (sx.abs() <= 16384.0) & (sy.abs() <= 16384.0)
+        t = tri.long()
+        bad = ~(ok[:, t[:, 0]] & ok[:, t[:, 1]] & ok[:, t[:, 2]])
+        return int(bad.sum())
+
+
+def _warn_dropped(pos, tri, height, width) -> None:
+    n = count_dropped_triangles(pos, tri, height, width)
+    if n:
+        import warnings
+        warnings.warn(f"tssplat_amd.dr.rasterize: {n} (view, triangle) pairs have a vertex at w <= 0 or beyond the +-16384-pixel guard "
+                      f"band and are DROPPED whole (nvdiffrast clips them)", RuntimeWarning, stacklevel=3)
 
 
 def _check_tri(tri: torch.Tensor, device) -> torch.Tensor:
@@ -107,6 +137,8 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
         raise RuntimeError("tssplat_amd.dr.rasterize: more than 2^24 - 1 triangles")
     if not (0 <= height <= 8192 and 0 <= width <= 8192):
         raise RuntimeError("tssplat_amd.dr.rasterize: resolution out of range (0 .. 8192 pixels per side)")
+    if _CHECK_DROPPED and tri.shape[0] > 0:
+        _warn_dropped(pos, tri, height, width)
     rast = _RasterizeFunc.apply(pos, tri, glctx, height, width)
     return rast, torch.empty((int(pos.shape[0]), height, width, 0), dtype=torch.float32, device=pos.device)
 
