@@ -3,7 +3,7 @@
 #   gpurun -- 'bash tools/profile_round.sh r02'
 # Raw output lands in gpurun_out/<round>p/; tools/summarize_prof.py condenses it into profiles/.
 set -u
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${ROUND}p
 mkdir -p $OUT
@@ -43,6 +43,11 @@ done
 python tools/ablate.py --spheres 512 --reps 10 > $OUT/ablate_512.log 2>&1
 python tools/ablate.py --spheres 512 --reps 5 --masks 0 --lds-request 100000 > $OUT/ablate_512_1wg.log 2>&1
 python tools/scaling_model.py $ROUND --out $OUT/scaling_model.json > $OUT/scaling_model.log 2>&1
+# round 4: production kernel + stamps, host cost of the operator surface (C++ autograd nodes), explicit operator, config 5 on the reference's object
+python tools/ablate.py --stamps-only --spheres 512 --reps 50 > $OUT/stamps_512.log 2>&1
+python tools/host_overhead.py > $OUT/host_overhead.txt 2>&1
+python tools/bench_operator.py > $OUT/bench_operator.txt 2>&1
+python tools/train_object.py > $OUT/train_mario.json 2> $OUT/train_mario.log
 # drop the bulky per-dispatch traces, keep stats + counters
 find $OUT -name "*kernel_trace.csv" -size +2M -delete
 ls $OUT | head -50
