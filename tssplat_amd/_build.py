@@ -87,7 +87,9 @@ def build_variant(name: str, extra_device_flags: list[str]) -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile (if stale) and return the path of libtssplat_amd.so."""
-    stamp = os.path.join(_OBJ, "digest")
+    # the stamp sits NEXT TO the library (not under _obj/, which does not travel to the GPU box): a snapshot that carries an
+    # up-to-date library is used as it is there instead of being rebuilt by the first import on every fresh box
+    stamp = LIB + ".digest"
     digest = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
         return LIB
@@ -123,7 +125,7 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     loader hands it), in-tree like the library so that it travels to the GPU box with the snapshot."""
     import sysconfig
     src = os.path.join(CSRC, "torch_autograd.cpp")
-    stamp = os.path.join(_OBJ, "torch_ext_digest")
+    stamp = TORCH_EXT + ".digest"
     import torch
     from torch.utils import cpp_extension as ce
     h = hashlib.sha256(open(src, "rb").read())
