@@ -319,14 +319,23 @@ int tsamd_rasterize_backward(const float *pos_clip_dev, int64_t batch, int64_t n
  * edge_partner_dev [3 * n_triangles] i32 is the topology table (nvdiffrast's topology hash): built once per triangle list by
  * tsamd_antialias_topology with a workspace of tsamd_antialias_topology_workspace_bytes(n_triangles).
  * color_dev / out_dev / grad_*: [batch, height, width, n_channels] f32.  The backward recomputes the analysis (no state is
- * kept between the calls); grad_color_dev and grad_pos_dev ([batch, n_vertices, 4], zero-filled first) may each be NULL. */
+ * kept between the calls); grad_color_dev and grad_pos_dev ([batch, n_vertices, 4], zero-filled first) may each be NULL.
+ * prepared_dev is OPTIONAL (NULL: everything is computed per use, identical results): tsamd_antialias_prepare fills it
+ * (tsamd_antialias_prepared_bytes bytes) from the same rast_dev / pos_clip_dev / tri_dev / edge_partner_dev / sizes with (1) the
+ * window coordinates of every (view, vertex) in float64, (2) a 2-bit-per-pixel mask of the pixel pairs with two different
+ * triangle ids, (3) per (view, triangle) which of its edges can blend at all (no partner, or a fold).  One prepared buffer
+ * serves the forward and the backward call: the image is scanned once instead of twice, the analysis of a pair on an
+ * interior triangle boundary ends at one byte, and no float64 division is left in it. */
 int64_t tsamd_antialias_topology_workspace_bytes(int64_t n_triangles);
 int tsamd_antialias_topology(const int32_t *tri_dev, int64_t n_triangles, void *workspace_dev, int32_t *edge_partner_dev, void *stream);
-int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
-                    int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
+int64_t tsamd_antialias_prepared_bytes(int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width);
+int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch,
+                            int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, void *prepared_dev, void *stream);
+int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const void *prepared_dev, const int32_t *tri_dev,
+                    const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
                     void *stream);
-int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev,
-                             const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const void *prepared_dev,
+                             const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
                              int32_t n_channels, const float *grad_out_dev, float pos_gradient_boost, float *grad_color_dev, float *grad_pos_dev,
                              void *stream);
 

@@ -237,10 +237,14 @@ def test_c_abi_checks_antialias_arguments():
     assert lib.tsamd_antialias_topology_workspace_bytes(10) == 64 * 16 + 30 * 4
     assert lib.tsamd_antialias_topology(None, 5, None, None, None) == 1
     assert lib.tsamd_antialias_topology(None, 0, None, None, None) == 0
-    assert lib.tsamd_antialias(None, None, None, None, None, 1, 3, 1, 4, 4, 0, None, None) == 1              # no channels
-    assert lib.tsamd_antialias(None, None, None, None, None, 1, 3, 1, 4, 4, 1, None, None) == 1              # null images
-    assert lib.tsamd_antialias(None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, None) == 0              # empty image
-    assert lib.tsamd_antialias_backward(None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, 1.0, None, None, None) == 1   # no output asked for
+    assert lib.tsamd_antialias(None, None, None, None, None, None, 1, 3, 1, 4, 4, 0, None, None) == 1        # no channels
+    assert lib.tsamd_antialias(None, None, None, None, None, None, 1, 3, 1, 4, 4, 1, None, None) == 1        # null images
+    assert lib.tsamd_antialias(None, None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, None) == 0        # empty image
+    assert lib.tsamd_antialias_backward(None, None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, 1.0, None, None, None) == 1   # no output asked for
+    assert lib.tsamd_antialias_prepared_bytes(2, 5, 7, 4, 8) == 3 * 256                                       # windows | pair masks | edge flags, each padded
+    assert lib.tsamd_antialias_prepared_bytes(-1, 5, 7, 4, 8) == -1
+    assert lib.tsamd_antialias_prepare(None, None, None, None, 1, 3, 1, 4, 4, None, None) == 1                # null buffers
+    assert lib.tsamd_antialias_prepare(None, None, None, None, 0, 0, 0, 4, 4, None, None) == 0                # nothing to do
     assert lib.tsamd_rasterize_backward(None, 1, 3, None, 1, 4, 4, None, None, None, None) == 1
     assert b"null" in lib.tsamd_last_error()
 
@@ -379,10 +383,12 @@ def test_topology_table_matches_the_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prepare", [True, False])
 @pytest.mark.parametrize("kind,spheres,views,res,channels", [("kuhn4", 3, 2, (64, 64), 1), ("kuhn8", 5, 3, (128, 96), 3)])
-def test_antialias_forward_backward(kind, spheres, views, res, channels):
+def test_antialias_forward_backward(kind, spheres, views, res, channels, prepare, monkeypatch):
     import torch
     import tssplat_amd.dr as dr
+    monkeypatch.setattr(dr, "PREPARE_ANTIALIAS", prepare)      # both forms of the analysis (tables per view / everything per pixel pair)
     pos_clip, tri, _ = _surface_scene(kind, spheres, views)
     ctx = dr.RasterizeCudaContext()
     tri_d = torch.from_numpy(tri).cuda()
@@ -408,8 +414,24 @@ def test_antialias_forward_backward(kind, spheres, views, res, channels):
     assert np.abs(gp).max() > 0
     assert np.abs(pos.grad.cpu().numpy() - gp).max() <= 2e-5 * np.abs(gp).max()
     # an explicit topology hash gives the same image (up to the order of the fp32 atomics on pixels with two blends)
-    out2 = dr.antialias(col.detach(), rast, pos.detach(), tri_d, topology_hash=dr.antialias_construct_topology_hash(tri_d))
+    topo = dr.antialias_construct_topology_hash(tri_d)
+    out2 = dr.antialias(col.detach(), rast, pos.detach(), tri_d, topology_hash=topo)
     assert (out2 - out.detach()).abs().max().item() <= 1e-6
+    # the C ABI without the prepared buffer (prepared_dev = NULL: windows and pair detection per use) takes the same decisions
+    from tssplat_amd import _capi
+    lib = _capi.load()
+    B, H, W, Cn = col.shape
+    out3 = torch.empty_like(col)
+    cd, pd = col.detach().contiguous(), pos.detach().contiguous()
+    _capi.check(lib.tsamd_antialias(cd.data_ptr(), rast.data_ptr(), pd.data_ptr(), None, tri_d.data_ptr(), topo.opp.data_ptr(), B, pd.shape[1],
+                                    tri_d.shape[0], H, W, Cn, out3.data_ptr(), None))
+    gc3, gp3, gd = torch.empty_like(cd), torch.empty_like(pd), torch.from_numpy(g).cuda()
+    _capi.check(lib.tsamd_antialias_backward(cd.data_ptr(), rast.data_ptr(), pd.data_ptr(), None, tri_d.data_ptr(), topo.opp.data_ptr(), B,
+                                             pd.shape[1], tri_d.shape[0], H, W, Cn, gd.data_ptr(), 2.0, gc3.data_ptr(), gp3.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (out3 - out.detach()).abs().max().item() <= 1e-6
+    assert (gc3 - col.grad).abs().max().item() <= 1e-5 * max(1.0, np.abs(gc).max())
+    assert (gp3 - pos.grad).abs().max().item() <= 2e-5 * np.abs(gp).max()
 
 
 @pytest.mark.gpu

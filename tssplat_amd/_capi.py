@@ -141,10 +141,13 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p]),
     "tsamd_antialias_topology_workspace_bytes": (C.c_int64, [C.c_int64]),
     "tsamd_antialias_topology": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "tsamd_antialias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
-                                  C.c_int32, C.c_void_p, C.c_void_p]),
-    "tsamd_antialias_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
-                                           C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tsamd_antialias_prepared_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tsamd_antialias_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p]),
+    "tsamd_antialias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "tsamd_antialias_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     # surface glue
     "tsamd_extract_surface": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
                                       C.POINTER(C.c_int64)]),

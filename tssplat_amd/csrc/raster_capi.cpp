@@ -117,8 +117,28 @@ int check_antialias(int64_t batch, int64_t n_vertices, int64_t n_triangles, int3
 }
 }  // namespace
 
-int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
-                    int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
+int64_t tsamd_antialias_prepared_bytes(int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width)
+{
+    if (check_image(batch, height, width) != TSAMD_OK || n_vertices < 0 || n_triangles < 0) return -1;
+    return tsamd::antialias_prepared_bytes(batch, n_vertices, n_triangles, height, width);
+}
+
+int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch,
+                            int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, void *prepared_dev, void *stream)
+{
+    int rc = check_antialias(batch, n_vertices, n_triangles, height, width, 1);
+    if (rc) return rc;
+    const int64_t pixels = batch * int64_t(height) * width;
+    if ((pixels > 0 || batch * n_vertices > 0) && !prepared_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "prepared_dev is null");
+    if ((pixels > 0 && !rast_dev) || (batch * n_vertices > 0 && !pos_clip_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "rast_dev / pos_clip_dev is null");
+    if (batch * n_triangles > 0 && (!tri_dev || !edge_partner_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "tri_dev / edge_partner_dev is null");
+    TSAMD_HIP(tsamd::launch_antialias_prepare(rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height, width, prepared_dev,
+                                              static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const void *prepared_dev, const int32_t *tri_dev,
+                    const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
                     void *stream)
 {
     int rc = check_antialias(batch, n_vertices, n_triangles, height, width, n_channels);
@@ -127,13 +147,13 @@ int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *
     if (pixels > 0 && (!color_dev || !rast_dev || !out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "color_dev / rast_dev / out_dev is null");
     if (pixels > 0 && n_triangles > 0 && (!pos_clip_dev || !tri_dev || !edge_partner_dev))
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev / edge_partner_dev is null");
-    TSAMD_HIP(tsamd::launch_antialias(color_dev, rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height, width,
+    TSAMD_HIP(tsamd::launch_antialias(color_dev, rast_dev, pos_clip_dev, prepared_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height, width,
                                       n_channels, out_dev, static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }
 
-int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev,
-                             const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const void *prepared_dev,
+                             const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
                              int32_t n_channels, const float *grad_out_dev, float pos_gradient_boost, float *grad_color_dev, float *grad_pos_dev,
                              void *stream)
 {
@@ -144,7 +164,7 @@ int tsamd_antialias_backward(const float *color_dev, const float *rast_dev, cons
     if (pixels > 0 && (!color_dev || !rast_dev || !grad_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "color_dev / rast_dev / grad_out_dev is null");
     if (pixels > 0 && n_triangles > 0 && (!pos_clip_dev || !tri_dev || !edge_partner_dev))
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev / edge_partner_dev is null");
-    TSAMD_HIP(tsamd::launch_antialias_backward(color_dev, rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height,
+    TSAMD_HIP(tsamd::launch_antialias_backward(color_dev, rast_dev, pos_clip_dev, prepared_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height,
                                                width, n_channels, grad_out_dev, pos_gradient_boost, grad_color_dev, grad_pos_dev,
                                                static_cast<hipStream_t>(stream)));
     return TSAMD_OK;

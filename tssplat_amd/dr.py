@@ -228,22 +228,36 @@ def _topology_for(tri: torch.Tensor) -> TopologyHash:
     return topo
 
 
+# None: decide per call (see _AntialiasFunc.forward); True / False force the prepared / the per-pair form of the antialias analysis
+PREPARE_ANTIALIAS = None
+
+
 class _AntialiasFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, color, rast, pos, tri, opp, boost):
         B, H, W, Cn = (int(k) for k in color.shape)
         V, T = int(pos.shape[1]), int(tri.shape[0])
         out = torch.empty_like(color)
+        # window coordinates per (view, vertex), mask of the pixel pairs on two triangles, edge flags per (view, triangle): once
+        # for the forward and the backward analysis -- when the mesh is small against the image (the reference's use: one object,
+        # 120 views x 512^2).  With more triangles than pixels the per-vertex / per-triangle tables cost more than they save
+        # (512 spheres in 8 views: 0.32 against 0.16 ms) and the kernels work everything out per pixel pair.
+        prepare = PREPARE_ANTIALIAS if PREPARE_ANTIALIAS is not None else 4 * (V + T) <= H * W
+        win = torch.empty((int(_lib.tsamd_antialias_prepared_bytes(B, V, T, H, W)) if prepare else 0,), dtype=torch.uint8, device=color.device)
         with _device_ctx(color.device):
-            _capi.check(_lib.tsamd_antialias(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W, Cn,
-                                             out.data_ptr(), _stream_ptr(color.device)))
-        ctx.save_for_backward(color, rast, pos, tri, opp)
+            stream = _stream_ptr(color.device)
+            if prepare:
+                _capi.check(_lib.tsamd_antialias_prepare(rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W,
+                                                         win.data_ptr(), stream))
+            _capi.check(_lib.tsamd_antialias(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), win.data_ptr() if prepare else None, tri.data_ptr(),
+                                             opp.data_ptr(), B, V, T, H, W, Cn, out.data_ptr(), stream))
+        ctx.save_for_backward(color, rast, pos, tri, opp, win)
         ctx.boost = float(boost)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        color, rast, pos, tri, opp = ctx.saved_tensors
+        color, rast, pos, tri, opp, win = ctx.saved_tensors
         B, H, W, Cn = (int(k) for k in color.shape)
         V, T = int(pos.shape[1]), int(tri.shape[0])
         g = grad_out.contiguous()
@@ -252,8 +266,9 @@ class _AntialiasFunc(torch.autograd.Function):
         if grad_color is None and grad_pos is None:
             return None, None, None, None, None, None
         with _device_ctx(color.device):
-            _capi.check(_lib.tsamd_antialias_backward(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W,
-                                                      Cn, g.data_ptr(), ctx.boost, None if grad_color is None else grad_color.data_ptr(),
+            _capi.check(_lib.tsamd_antialias_backward(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), win.data_ptr() if win.numel() else None,
+                                                      tri.data_ptr(), opp.data_ptr(),
+                                                      B, V, T, H, W, Cn, g.data_ptr(), ctx.boost, None if grad_color is None else grad_color.data_ptr(),
                                                       None if grad_pos is None else grad_pos.data_ptr(), _stream_ptr(color.device)))
         return grad_color, None, grad_pos, None, None, None
 
