@@ -413,6 +413,37 @@ def test_config4_full_size_properties(ext):
     assert abs(gs.sum(axis=(1, 2)).sum() - gos.sum(axis=(1, 2)).sum()) <= 1e-4 * np.abs(gos).sum() / np.sqrt(go.size)
 
 
+def test_replicated_sphere_beyond_4_gib(ext):
+    """64-bit addressing at scale: 1 700 copies of ONE deformed kuhn19 sphere (69.96 M tets, plan planes > 4 GiB, staging rows,
+    finish lists and tile blobs addressed far beyond 2^32 bytes).  Every copy is tiled identically (the plan is a function of
+    the rest geometry), so every copy's gradient must be BIT-identical to the single-sphere evaluation's, and the energy
+    S times the single sphere's.  (profiles/r04_bench_kuhn19x8192.json runs 337 M tets / 29 GB the same way.)"""
+    from tssplat_amd import scenes
+    S = 1700
+    sc = scenes.make_scene("kuhn19", 1)
+    n1, m1 = sc.n_vertices, sc.n_tets
+    x1 = scenes.deform(sc, 0.3)                       # many inverted tets: both energy terms live
+    ts1 = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    c1, c2 = 2e-4, 2e-4
+    e1, g1 = _eval_gpu(ext, ts1, x1, c1, c2, 4)
+    rest = np.tile(sc.rest, (S, 1))
+    tets = (sc.tets[None].astype(np.int64) + (np.arange(S, dtype=np.int64) * n1)[:, None, None]).reshape(-1, 4).astype(np.int32)
+    ts = ext.TetSpheres(rest.reshape(-1), tets.reshape(-1))
+    info = ts.plan_info()
+    assert info["n_tets"] == S * m1 and info["n_components"] == S
+    assert info["total_slots"] * 4 * info["n_planes"] > 2 ** 32 and info["device_bytes"] > 2 ** 32
+    del rest, tets
+    x = torch.from_numpy(np.tile(x1, (S, 1))).cuda()
+    e = ext.forward(x, ts, c1, c2, 4)
+    g = ext.backward(torch.tensor(1.0), x, ts, c1, c2, 4)
+    assert abs(float(e) - S * e1) <= 2e-6 * abs(S * e1)
+    gs = g.reshape(S, n1, 3)
+    ref = torch.from_numpy(g1.astype(np.float32)).cuda()
+    assert torch.equal(gs[0], ref), "the first copy differs from the single-sphere evaluation"
+    same = (gs == ref[None]).all(dim=2).all(dim=1)
+    assert bool(same.all()), f"copies {torch.nonzero(~same).flatten()[:8].tolist()} differ from the first"
+
+
 def test_degenerate_inputs(ext):
     """Empty batches and vertices no tet references: energy 0, gradient 0 (never uninitialised)."""
     from tssplat_amd import scenes
