@@ -284,14 +284,15 @@ int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev
  * nvdiffrast is a separate library (not vendored by the reference, version unpinned): the semantics implemented are a
  * restatement of its published algorithm, fixed in every detail by oracle/raster_oracle.py -- clip-space input, OpenGL
  * conventions (row 0 = bottom), no culling, nearest depth, output (u, v, z/w, triangle_id + 1), 0 = background.  PARITY
- * UNPINNED (no nvdiffrast here).  Not offered: polygon clipping (a triangle with a vertex at w <= 0 is dropped), depth
- * peeling, `ranges`, image-space derivatives (grad_db).  Limits: height, width <= 8192 (window coordinates are snapped to
- * 1/256 pixel and kept within +-16384 pixels; a triangle with a vertex beyond that guard band -- or at w <= 0 -- is dropped
- * whole), n_triangles <= 2^24 - 1 (the id + 1 travels as a float32).  Stateless: the caller owns all buffers and
+ * UNPINNED (no nvdiffrast here).  Clipping: against the near plane (z + w >= 0) for triangles with a vertex at w <= 0 (the
+ * clipped polygon is rasterised under the triangle's own id; pixels beyond the far plane or the image fail their own tests).
+ * Not offered: depth peeling, `ranges`, image-space derivatives (grad_db).  Limits: height, width <= 8192 (window coordinates
+ * are snapped to 1/256 pixel and kept within +-16384 pixels; a triangle with a vertex beyond that guard band, or a non-finite
+ * one, is dropped whole), n_triangles <= 2^24 - 1 (the id + 1 travels as a float32).  Stateless: the caller owns all buffers and
  * the current HIP device is used.  pos_clip_dev: [batch, n_vertices, 4] f32; tri_dev: [n_triangles, 3] i32;
  * rast: [batch, height, width, 4] f32; attr_dev: [attr_batch (1 or batch), n_vertices, n_channels] f32.
  */
-/* workspace: one 64-bit depth key per pixel and one 16-byte snapped vertex per (view, vertex) */
+/* workspace: one 64-bit depth key per pixel, one 16-byte snapped vertex per (view, vertex), one flag per view */
 int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width);
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
                     int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *stream);

@@ -68,54 +68,112 @@ def _top_left(dx: int, dy: int) -> bool:
     return dy < 0 or (dy == 0 and dx < 0)
 
 
+def _snap_point(x, y, z, w, height: int, width: int):
+    """``snap_vertices`` for one float64 clip-space point (a vertex made by the near-plane clip); None when it cannot be snapped."""
+    if not (np.isfinite(x) and np.isfinite(y) and np.isfinite(z) and np.isfinite(w) and w > 0.0):
+        return None
+    xs = ((x / w) * 0.5 + 0.5) * float(width)
+    ys = ((y / w) * 0.5 + 0.5) * float(height)
+    X = np.floor(xs * float(SUB) + 0.5)
+    Y = np.floor(ys * float(SUB) + 0.5)
+    if not (abs(X) <= COORD_LIMIT and abs(Y) <= COORD_LIMIT):
+        return None
+    return int(X), int(Y), np.float32(z / w)
+
+
+def clip_near(p3: np.ndarray):
+    """Sutherland-Hodgman clip of ONE triangle (``p3[3, 4]`` float64 clip-space rows) against the near plane ``z + w >= 0``.
+
+    Returns the polygon as a list of entries ``("v", k)`` (original vertex k, kept) or ``("i", point[4])`` (an intersection, always
+    computed FROM the inside vertex TOWARDS the outside one -- ``a + (d_a / (d_a - d_b)) * (b - a)``, one rounding per operation --
+    so that the two triangles sharing a clipped edge make the same point)."""
+    d = p3[:, 2] + p3[:, 3]
+    inside = d >= 0.0
+    poly = []
+    for k in range(3):
+        n = (k + 1) % 3
+        if inside[k]:
+            poly.append(("v", k))
+        if inside[k] != inside[n]:
+            a, b = (k, n) if inside[k] else (n, k)
+            t = d[a] / (d[a] - d[b])
+            poly.append(("i", p3[a] + t * (p3[b] - p3[a])))
+    return poly
+
+
+def _cover(key, t, v0, v1, v2, height, width):
+    """Coverage + depth of ONE snapped triangle ``((x, y, zw) x 3)`` into the key image, under triangle id ``t``."""
+    (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = v0, v1, v2
+    area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
+    if area == 0:
+        return
+    if area < 0:                                    # orient counter-clockwise: swap vertices 1 and 2
+        x1, y1, z1, x2, y2, z2 = x2, y2, z2, x1, y1, z1
+    # pixel range whose centres can lie inside (centre of pixel i = i * 256 + 128 in sub-pixel units)
+    px0 = max(0, (min(x0, x1, x2) - SUB // 2 + SUB - 1) // SUB)
+    px1 = min(width - 1, (max(x0, x1, x2) - SUB // 2) // SUB)
+    py0 = max(0, (min(y0, y1, y2) - SUB // 2 + SUB - 1) // SUB)
+    py1 = min(height - 1, (max(y0, y1, y2) - SUB // 2) // SUB)
+    if px0 > px1 or py0 > py1:
+        return
+    cx = (np.arange(px0, px1 + 1, dtype=np.int64) * SUB + SUB // 2)[None, :]
+    cy = (np.arange(py0, py1 + 1, dtype=np.int64) * SUB + SUB // 2)[:, None]
+    # E_k = edge function of the edge OPPOSITE vertex k (weights of vertex k), >= 0 inside
+    e0 = (x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1)
+    e1 = (x0 - x2) * (cy - y2) - (y0 - y2) * (cx - x2)
+    e2 = (x1 - x0) * (cy - y0) - (y1 - y0) * (cx - x0)
+    inside = np.ones(e0.shape, dtype=bool)
+    for e, (dx, dy) in ((e0, (x2 - x1, y2 - y1)), (e1, (x0 - x2, y0 - y2)), (e2, (x1 - x0, y1 - y0))):
+        inside &= (e > 0) | ((e == 0) & _top_left(dx, dy))
+    if not inside.any():
+        return
+    # depth plane through the three snapped vertices (area > 0 after the orientation): float32, one rounding per operation
+    f32 = np.float32
+    A = f32(np.float64(abs(area)))
+    d1, d2 = z1 - z0, z2 - z0
+    zx = (d1 * f32(y2 - y0) - d2 * f32(y1 - y0)) / A
+    zy = (d2 * f32(x1 - x0) - d1 * f32(x2 - x0)) / A
+    zw = (z0 + zx * (cx - x0).astype(f32)) + zy * (cy - y0).astype(f32)
+    assert zw.dtype == np.float32
+    inside &= (zw >= f32(-1.0)) & (zw <= f32(1.0))
+    q = (zw + f32(1.0)) * f32(DEPTH_SCALE)                  # float32, in [0, 2^32]: the scaling is exact
+    q = np.where(q >= f32(4294967296.0), np.uint64(0xFFFFFFFF), np.where(inside, q, f32(0)).astype(np.uint64))
+    k = (q << np.uint64(32)) | np.uint64(t)
+    sub = key[py0:py1 + 1, px0:px1 + 1]
+    np.minimum(sub, np.where(inside, k, NO_FRAGMENT), out=sub)
+
+
 def rasterize_ids(pos_clip: np.ndarray, tri: np.ndarray, height: int, width: int) -> np.ndarray:
-    """Depth keys ``(depth32 << 32) | triangle`` per pixel of ONE view, ``NO_FRAGMENT`` where nothing covers the centre."""
+    """Depth keys ``(depth32 << 32) | triangle`` per pixel of ONE view, ``NO_FRAGMENT`` where nothing covers the centre.
+
+    A triangle whose three vertices are finite but not all in front of the camera (``w <= 0`` somewhere) is clipped against the
+    near plane (``clip_near``), its polygon snapped like any vertex and rasterised as a fan under the triangle's own id (what
+    nvdiffrast's triangle set-up does with its frustum clipper; ``resolve`` works from the unclipped vertices either way).  A
+    triangle with a non-finite vertex, or one that cannot be snapped (beyond the +-16384-pixel guard band), is dropped."""
     X, Y, ZW, ok = snap_vertices(pos_clip, height, width)
+    p64 = np.asarray(pos_clip, dtype=np.float32).astype(np.float64)
+    finite = np.isfinite(p64).all(axis=1)
     tri = np.asarray(tri, dtype=np.int64).reshape(-1, 3)
     key = np.full((height, width), NO_FRAGMENT, dtype=np.uint64)
     for t in range(tri.shape[0]):
-        i0, i1, i2 = tri[t]
-        if not (ok[i0] and ok[i1] and ok[i2]):
+        i = tri[t]
+        if ok[i[0]] and ok[i[1]] and ok[i[2]]:
+            _cover(key, t, *[(int(X[k]), int(Y[k]), ZW[k]) for k in i], height, width)
             continue
-        x0, y0, x1, y1, x2, y2 = int(X[i0]), int(Y[i0]), int(X[i1]), int(Y[i1]), int(X[i2]), int(Y[i2])
-        z0, z1, z2 = ZW[i0], ZW[i1], ZW[i2]                     # numpy float32 scalars: every operation below rounds to float32
-        area = (x1 - x0) * (y2 - y0) - (y1 - y0) * (x2 - x0)
-        if area == 0:
+        behind = finite[i] & (p64[i, 3] <= 0.0)
+        if not (ok[i] | behind).all():
+            continue                                 # a vertex that is not finite, or beyond the guard band: dropped, not clipped
+        pts = []
+        for kind, what in clip_near(p64[i]):
+            if kind == "v":
+                v = i[what]
+                pts.append((int(X[v]), int(Y[v]), ZW[v]) if ok[v] else None)     # (kept vertices use the shared snap)
+            else:
+                pts.append(_snap_point(what[0], what[1], what[2], what[3], height, width))
+        if len(pts) < 3 or any(q is None for q in pts):
             continue
-        if area < 0:                                    # orient counter-clockwise: swap vertices 1 and 2
-            x1, y1, z1, x2, y2, z2 = x2, y2, z2, x1, y1, z1
-        # pixel range whose centres can lie inside (centre of pixel i = i * 256 + 128 in sub-pixel units)
-        px0 = max(0, (min(x0, x1, x2) - SUB // 2 + SUB - 1) // SUB)
-        px1 = min(width - 1, (max(x0, x1, x2) - SUB // 2) // SUB)
-        py0 = max(0, (min(y0, y1, y2) - SUB // 2 + SUB - 1) // SUB)
-        py1 = min(height - 1, (max(y0, y1, y2) - SUB // 2) // SUB)
-        if px0 > px1 or py0 > py1:
-            continue
-        cx = (np.arange(px0, px1 + 1, dtype=np.int64) * SUB + SUB // 2)[None, :]
-        cy = (np.arange(py0, py1 + 1, dtype=np.int64) * SUB + SUB // 2)[:, None]
-        # E_k = edge function of the edge OPPOSITE vertex k (weights of vertex k), >= 0 inside
-        e0 = (x2 - x1) * (cy - y1) - (y2 - y1) * (cx - x1)
-        e1 = (x0 - x2) * (cy - y2) - (y0 - y2) * (cx - x2)
-        e2 = (x1 - x0) * (cy - y0) - (y1 - y0) * (cx - x0)
-        inside = np.ones(e0.shape, dtype=bool)
-        for e, (dx, dy) in ((e0, (x2 - x1, y2 - y1)), (e1, (x0 - x2, y0 - y2)), (e2, (x1 - x0, y1 - y0))):
-            inside &= (e > 0) | ((e == 0) & _top_left(dx, dy))
-        if not inside.any():
-            continue
-        # depth plane through the three snapped vertices (area > 0 after the orientation): float32, one rounding per operation
-        f32 = np.float32
-        A = f32(np.float64(abs(area)))
-        d1, d2 = z1 - z0, z2 - z0
-        zx = (d1 * f32(y2 - y0) - d2 * f32(y1 - y0)) / A
-        zy = (d2 * f32(x1 - x0) - d1 * f32(x2 - x0)) / A
-        zw = (z0 + zx * (cx - x0).astype(f32)) + zy * (cy - y0).astype(f32)
-        assert zw.dtype == np.float32
-        inside &= (zw >= f32(-1.0)) & (zw <= f32(1.0))
-        q = (zw + f32(1.0)) * f32(DEPTH_SCALE)                  # float32, in [0, 2^32]: the scaling is exact
-        q = np.where(q >= f32(4294967296.0), np.uint64(0xFFFFFFFF), np.where(inside, q, f32(0)).astype(np.uint64))
-        k = (q << np.uint64(32)) | np.uint64(t)
-        sub = key[py0:py1 + 1, px0:px1 + 1]
-        np.minimum(sub, np.where(inside, k, NO_FRAGMENT), out=sub)
+        for k in range(1, len(pts) - 1):
+            _cover(key, t, pts[0], pts[k], pts[k + 1], height, width)
     return key
 
 

@@ -78,7 +78,7 @@ def test_dropped_triangles_and_background():
     H = W = 8
     pos, tri = _quad()
     behind = pos.copy()
-    behind[0, 3] = -1.0                                             # a vertex behind the eye: no clipping in this slice, dropped
+    behind[:, 3] = -1.0                                             # every vertex behind the eye: nothing to clip, nothing drawn
     assert (R.rasterize(behind, tri[:1], (H, W)) == 0).all()
     far = pos.copy()
     far[:, 2] = 2.0                                                 # z/w = 2: beyond the far plane, every fragment dropped
@@ -88,6 +88,54 @@ def test_dropped_triangles_and_background():
     assert (R.rasterize(nan, tri[:1], (H, W)) == 0).all()
     degenerate = np.array([[0, 1, 1]], dtype=np.int32)
     assert (R.rasterize(pos, degenerate, (H, W)) == 0).all()
+
+
+def _ground_scene():
+    """A large ground triangle under a perspective camera at height 1 looking along -z: its near vertices lie BEHIND the eye."""
+    near, far, f = 0.1, 50.0, 1.0 / np.tan(np.radians(30.0))
+    proj = np.array([[f, 0, 0, 0], [0, f, 0, 0], [0, 0, (far + near) / (near - far), 2 * far * near / (near - far)], [0, 0, -1, 0]])
+    view = np.eye(4)
+    view[1, 3] = -1.0
+    mvp = proj @ view
+
+    def clip(v):
+        return (np.concatenate([v, np.ones((len(v), 1))], axis=1) @ mvp.T).astype(np.float32)
+    return clip
+
+
+def test_near_plane_clipping():
+    """A triangle with vertices at w <= 0 is clipped against the near plane, not dropped: it covers the same pixels as the
+    same surface cut into a piece in front of the camera and a piece that straddles the eye plane, z/w and (u, v) agree with the
+    unclipped plane, and a triangle entirely behind the camera draws nothing."""
+    H = W = 48
+    clip = _ground_scene()
+    A, B, C = np.array([-30.0, 0, 8]), np.array([30.0, 0, 8]), np.array([0.0, 0, -40])     # A, B behind the eye (z > 0), C far ahead
+    pos = clip(np.stack([A, B, C]))
+    assert (pos[:2, 3] <= 0).all() and pos[2, 3] > 0
+    whole = R.rasterize(pos, np.array([[0, 1, 2]], np.int32), (H, W))[0]
+    assert (whole[..., 3] > 0).sum() > 200                                               # the ground is visible below the horizon
+    assert (whole[H // 2 + 2:, :, 3] == 0).all()                                         # ... and nowhere above it
+    # the same surface in two pieces: cut along z = -2 (in front of the near plane at z = -0.1)
+    t = (-2.0 - A[2]) / (C[2] - A[2])
+    P, Q = A + t * (C - A), B + t * (C - B)
+    pos2 = clip(np.stack([A, B, C, P, Q]))
+    parts = R.rasterize(pos2, np.array([[3, 4, 2], [0, 1, 4], [0, 4, 3]], np.int32), (H, W))[0]
+    cover_w, cover_p = whole[..., 3] > 0, parts[..., 3] > 0
+    assert (cover_w != cover_p).sum() <= 2                                               # (the cut's end points are rounded to float32)
+    both = cover_w & cover_p
+    assert np.abs(whole[..., 2] - parts[..., 2])[both].max() < 2e-5                      # same depth plane
+    # barycentrics of the unclipped triangle reproduce the world position of every covered pixel's ray on the ground plane
+    jj, ii = np.nonzero(cover_w)
+    u, v = whole[jj, ii, 0], whole[jj, ii, 1]
+    world = u[:, None] * A + v[:, None] * B + (1 - u - v)[:, None] * C
+    hit = clip(world)
+    ndc = hit[:, :2] / hit[:, 3:4]
+    assert np.abs((ndc[:, 0] * 0.5 + 0.5) * W - (ii + 0.5)).max() < 0.02 and np.abs((ndc[:, 1] * 0.5 + 0.5) * H - (jj + 0.5)).max() < 0.02
+    # polygon of the clip: two kept / one kept vertices
+    assert [k for k, _ in R.clip_near(pos.astype(np.float64))] == ["i", "v", "i"]
+    assert [k for k, _ in R.clip_near(pos[[2, 0, 2]].astype(np.float64))].count("v") == 2
+    behind_all = clip(np.stack([A, B, np.array([0.0, 0, 3])]))
+    assert (R.rasterize(behind_all, np.array([[0, 1, 2]], np.int32), (H, W)) == 0).all()
 
 
 def test_interpolate_backward_is_the_adjoint():
@@ -108,7 +156,7 @@ def test_interpolate_backward_is_the_adjoint():
 
 def test_c_abi_rejects_bad_arguments():
     lib = _capi.load()
-    assert lib.tsamd_rasterize_workspace_bytes(8, 1000, 512, 512) == 8 * 512 * 512 * 8 + 8 * 1000 * 16
+    assert lib.tsamd_rasterize_workspace_bytes(8, 1000, 512, 512) == 8 * 512 * 512 * 8 + 8 * 1000 * 16 + 32      # keys, snapped vertices, view flags
     assert lib.tsamd_rasterize_workspace_bytes(-1, 3, 4, 4) == -1
     assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None) == 1          # null workspace / output
     assert b"null" in lib.tsamd_last_error()
@@ -527,14 +575,44 @@ def test_interpolate_bounds_on_foreign_rast():
     assert float(out0.abs().max()) == 0.0
 
 
+@pytest.mark.gpu
+def test_near_plane_clipping_on_gpu():
+    """Triangles that straddle the eye plane: ids bit-exact against the oracle's clip (ground plane under a camera, plus a random
+    soup pushed through the camera), in a batch whose second view needs no clipping at all."""
+    import torch
+    import tssplat_amd.dr as dr
+    H, W = 96, 80
+    clip = _ground_scene()
+    rng = np.random.default_rng(11)
+    ground = np.array([[-30.0, 0, 8], [30.0, 0, 8], [0.0, 0, -40], [-30, 0, -40], [30, 0, -40], [0, 0, 20]])
+    soup = rng.uniform(-3, 3, (60, 3)) + [0, 1, 0]                                   # around the eye at (0, 1, 0)
+    v = np.concatenate([ground, soup])
+    tri = np.concatenate([[[0, 1, 2], [0, 2, 3], [1, 4, 2], [0, 1, 5]], 6 + rng.integers(0, 60, (150, 3))]).astype(np.int32)
+    pos0 = clip(v)
+    assert ((pos0[:, 3] <= 0).sum() > 10) and ((pos0[:, 3] > 0).sum() > 10)
+    pos1 = clip(v * [1, 1, 0.2] - [0, 0, 6])                                        # everything in front of the camera
+    assert (pos1[:, 3] > 0).all()
+    pos = np.stack([pos0, pos1])
+    ref = R.rasterize(pos, tri, (H, W))
+    out, _ = dr.rasterize(dr.RasterizeCudaContext(), torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), resolution=[H, W], grad_db=False)
+    out = out.cpu().numpy()
+    assert (ref[0, ..., 3] > 0).sum() > 500
+    assert np.array_equal(out[..., 3], ref[..., 3])
+    hit = ref[..., 3] > 0
+    assert np.abs(out[..., :3] - ref[..., :3])[hit].max() <= 2e-4
+    # the clipped triangles took part: some winning triangle of view 0 has a vertex at w <= 0
+    ids = np.unique(ref[0, ..., 3][ref[0, ..., 3] > 0]).astype(int) - 1
+    assert (pos0[tri[ids], 3] <= 0).any()
+
+
 def test_dropped_triangle_counter():
     """dr.count_dropped_triangles (TSSPLAT_AMD_DR_CHECK=1 makes dr.rasterize warn with it): the (view, triangle) pairs this slice
-    drops whole where nvdiffrast would clip -- a vertex at w <= 0, not finite, or beyond the +-16384-pixel guard band."""
+    drops whole -- a vertex that is not finite or beyond the +-16384-pixel guard band (a finite vertex at w <= 0 is clipped)."""
     import torch
     import tssplat_amd.dr as dr
     pos = torch.tensor([[[0, 0, 0, 1.0], [1, 0, 0, 1], [0, 1, 0, -1.0], [0.5, 0.5, 0, 1], [float("nan"), 0, 0, 1], [4000.0, 0, 0, 1]],
                         [[0, 0, 0, 1.0], [1, 0, 0, 1], [0, 1, 0, 1.0], [0.5, 0.5, 0, 1], [0.0, 0, 0, 1], [0.0, 0, 0, 1]]])
     tri = torch.tensor([[0, 1, 2], [0, 1, 3], [0, 1, 4], [0, 1, 5]], dtype=torch.int32)
-    # view 0: w <= 0, fine, NaN, 4000 * 0.5 * 64 = 128 000 px -> three dropped; view 1: nothing dropped
-    assert dr.count_dropped_triangles(pos, tri, 64, 64) == 3
+    # view 0: w <= 0 (clipped, not dropped), fine, NaN, 4000 * 0.5 * 64 = 128 000 px -> two dropped; view 1: nothing dropped
+    assert dr.count_dropped_triangles(pos, tri, 64, 64) == 2
     assert dr.count_dropped_triangles(pos[1:], tri, 64, 64) == 0

@@ -26,7 +26,8 @@ extern "C" {
 int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width)
 {
     if (batch < 0 || n_vertices < 0 || height < 0 || width < 0) return -1;
-    return ((batch * int64_t(height) * int64_t(width) + 1) & ~int64_t(1)) * 8 + batch * n_vertices * 16;   // depth keys (padded to 16 B) + snapped vertices
+    // depth keys (padded to 16 B) + snapped vertices + one flag per view (has a vertex at w <= 0: near-plane clipping needed)
+    return ((batch * int64_t(height) * int64_t(width) + 1) & ~int64_t(1)) * 8 + batch * n_vertices * 16 + ((batch * 4 + 15) & ~int64_t(15));
 }
 
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles, int32_t height,

@@ -18,6 +18,8 @@
 // output per pixel); no MFMA anywhere.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "raster.h"
 
 // Coverage, depth and silhouette decisions repeat the oracle's operations one by one: a multiply and an add must round
@@ -45,24 +47,40 @@ constexpr int32_t kDropped = INT32_MIN;
 // oracle/raster_oracle.py::snap_vertices, operation by operation (explicitly rounded double intrinsics: no contraction).
 // One lane per (view, vertex): a vertex is snapped once per view, not once per triangle that uses it (six on a closed
 // surface).
-__global__ __launch_bounds__(256) void rasterize_snap_kernel(const float4 *pos, int64_t n, double width, double height, SnapRec *out)
+// (x, y, z, w) in float64 -> record; false (and x = kDropped) when w <= 0 or the window coordinates leave the coordinate range
+__device__ __forceinline__ bool snap_point(double x, double y, double z, double w, bool finite, double width, double height, SnapRec &r)
 {
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (gid >= n) return;
-    const float4 p = pos[gid];
-    const double x = double(p.x), y = double(p.y), z = double(p.z), w = double(p.w);
-    bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w) && p.w > 0.f;
+    bool ok = finite && w > 0.0;
     const double ws = ok ? w : 1.0;
     const double xs = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(x, ws), 0.5), 0.5), width);
     const double ys = __dmul_rn(__dadd_rn(__dmul_rn(__ddiv_rn(y, ws), 0.5), 0.5), height);
     const double X = floor(__dadd_rn(__dmul_rn(xs, double(kSub)), 0.5));
     const double Y = floor(__dadd_rn(__dmul_rn(ys, double(kSub)), 0.5));
     ok = ok && fabs(X) <= double(kCoordLimit) && fabs(Y) <= double(kCoordLimit);
-    SnapRec r;
     r.x = ok ? int32_t(X) : kDropped;
     r.y = ok ? int32_t(Y) : 0;
     r.zw = ok ? float(__ddiv_rn(z, ws)) : 0.f;
     r.pad = 0;
+    return ok;
+}
+
+// pad = kBehind marks a FINITE vertex at w <= 0: its triangles are not dropped but clipped against the near plane
+// (rasterize_clip_kernel); view_flags[b] != 0 tells that kernel that view b has such a vertex at all.
+constexpr uint32_t kBehind = 1u;
+
+__global__ __launch_bounds__(256) void rasterize_snap_kernel(const float4 *pos, int64_t n, int64_t n_vertices, double width, double height, SnapRec *out,
+                                                             uint32_t *view_flags)
+{
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (gid >= n) return;
+    const float4 p = pos[gid];
+    const bool finite = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && isfinite(p.w);
+    SnapRec r;
+    snap_point(double(p.x), double(p.y), double(p.z), double(p.w), finite, width, height, r);
+    if (finite && !(p.w > 0.f)) {
+        r.pad = kBehind;
+        view_flags[gid / n_vertices] = 1u;   // (every writer writes the same value)
+    }
     out[gid] = r;
 }
 
@@ -242,6 +260,112 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(cons
                              (long long)dy2 * kSub, (long long)dx0 * kSub, (long long)dx1 * kSub, (long long)dx2 * kSub, pl, (unsigned long long)t, width,
                              lane, q);
     drain(q, lane);
+}
+
+// ---- near-plane clipping (rare path) ----
+// oracle/raster_oracle.py::clip_near + rasterize_ids: a triangle with finite vertices of which some (not all) lie at w <= 0 is
+// clipped against z + w >= 0 in float64 (Sutherland-Hodgman, intersections computed from the inside vertex towards the outside
+// one), the polygon's new vertices are snapped like any vertex, and the fan is rasterised with the same integer edge functions,
+// the same float32 depth plane and the triangle's own id.  Only the views whose flag the snap kernel raised are visited -- no view
+// of an object inside the frustum -- with plain per-lane loops and direct atomics: correctness path, not speed.
+__device__ __forceinline__ void cover_clipped(SnapRec s0, SnapRec s1, SnapRec s2, unsigned long long tid, int height, int width, unsigned long long *image)
+{
+    const int32_t hs = int32_t(kSub / 2);
+    long long area = (long long)(s1.x - s0.x) * (s2.y - s0.y) - (long long)(s1.y - s0.y) * (s2.x - s0.x);
+    if (area == 0) return;
+    if (area < 0) {
+        const SnapRec tmp = s1;
+        s1 = s2;
+        s2 = tmp;
+        area = -area;
+    }
+    const int32_t minx = min(s0.x, min(s1.x, s2.x)), maxx = max(s0.x, max(s1.x, s2.x));
+    const int32_t miny = min(s0.y, min(s1.y, s2.y)), maxy = max(s0.y, max(s1.y, s2.y));
+    const int32_t px0 = max(0, (minx - hs + int32_t(kSub) - 1) >> kSubBits), px1 = min(width - 1, (maxx - hs) >> kSubBits);
+    const int32_t py0 = max(0, (miny - hs + int32_t(kSub) - 1) >> kSubBits), py1 = min(height - 1, (maxy - hs) >> kSubBits);
+    if (px0 > px1 || py0 > py1) return;
+    const float A = float(double(area));
+    const float d1 = s1.zw - s0.zw, d2 = s2.zw - s0.zw;
+    const float zx = (d1 * float(s2.y - s0.y) - d2 * float(s1.y - s0.y)) / A;
+    const float zy = (d2 * float(s1.x - s0.x) - d1 * float(s2.x - s0.x)) / A;
+    const long long dx0 = s2.x - s1.x, dy0 = s2.y - s1.y, dx1 = s0.x - s2.x, dy1 = s0.y - s2.y, dx2 = s1.x - s0.x, dy2 = s1.y - s0.y;
+    const long long b0 = top_left(int32_t(dx0), int32_t(dy0)) ? 0 : 1, b1 = top_left(int32_t(dx1), int32_t(dy1)) ? 0 : 1,
+                    b2 = top_left(int32_t(dx2), int32_t(dy2)) ? 0 : 1;
+    for (int32_t py = py0; py <= py1; ++py)
+        for (int32_t px = px0; px <= px1; ++px) {
+            const long long cx = (long long)px * kSub + hs, cy = (long long)py * kSub + hs;
+            const long long e0 = dx0 * (cy - s1.y) - dy0 * (cx - s1.x) - b0, e1 = dx1 * (cy - s2.y) - dy1 * (cx - s2.x) - b1,
+                            e2 = dx2 * (cy - s0.y) - dy2 * (cx - s0.x) - b2;
+            if ((e0 | e1 | e2) < 0) continue;
+            const float zw = (s0.zw + zx * float(int32_t(cx) - s0.x)) + zy * float(int32_t(cy) - s0.y);
+            if (!(zw >= -1.f && zw <= 1.f)) continue;
+            const float q = (zw + 1.f) * 2147483648.f;
+            const uint32_t depth = q >= 4294967296.f ? 0xFFFFFFFFu : uint32_t(q);
+            atomicMin(image + size_t(py) * size_t(width) + size_t(px), ((unsigned long long)depth << 32) | tid);
+        }
+}
+
+__device__ __forceinline__ void clip_one(const float4 *pos, const SnapRec *snapped, const int32_t *tri, int b, int64_t t, int64_t n_vertices, int height,
+                                         int width, unsigned long long *keys)
+{
+    const int32_t idx[3] = {tri[3 * t], tri[3 * t + 1], tri[3 * t + 2]};
+    if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0 || idx[0] >= n_vertices || idx[1] >= n_vertices || idx[2] >= n_vertices) return;
+    const SnapRec *sv = snapped + int64_t(b) * n_vertices;
+    const SnapRec s[3] = {sv[idx[0]], sv[idx[1]], sv[idx[2]]};
+    bool any_behind = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (s[k].x == kDropped && s[k].pad != kBehind) return;   // not finite, or beyond the guard band: dropped, not clipped
+        any_behind = any_behind || s[k].pad == kBehind;
+    }
+    if (!any_behind) return;   // (rasterize_bin_kernel has done this triangle)
+    const float4 *pv = pos + int64_t(b) * n_vertices;
+    double p[3][4], d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float4 v = pv[idx[k]];
+        p[k][0] = double(v.x), p[k][1] = double(v.y), p[k][2] = double(v.z), p[k][3] = double(v.w);
+        d[k] = __dadd_rn(p[k][2], p[k][3]);
+    }
+    SnapRec poly[4];
+    int n_poly = 0;
+    bool fail = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int n = (k + 1) % 3;
+        const bool in_k = d[k] >= 0.0, in_n = d[n] >= 0.0;
+        if (in_k) {
+            fail = fail || s[k].x == kDropped;   // inside the near plane and yet at w <= 0: not a projection this slice handles
+            poly[n_poly++] = s[k];
+        }
+        if (in_k != in_n) {
+            const int a = in_k ? k : n, o = in_k ? n : k;
+            const double tt = __ddiv_rn(d[a], __dsub_rn(d[a], d[o]));
+            double q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __dadd_rn(p[a][c], __dmul_rn(tt, __dsub_rn(p[o][c], p[a][c])));
+            SnapRec r;
+            const bool finite = isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && isfinite(q[3]);
+            fail = !snap_point(q[0], q[1], q[2], q[3], finite, double(width), double(height), r) || fail;
+            poly[n_poly++] = r;
+        }
+    }
+    if (fail || n_poly < 3) return;
+    unsigned long long *image = keys + size_t(b) * size_t(height) * size_t(width);
+    for (int k = 1; k + 1 < n_poly; ++k) cover_clipped(poly[0], poly[k], poly[k + 1], (unsigned long long)t, height, width, image);
+}
+
+// a small fixed grid strides over the triangles of the flagged views only: a batch that needs no clipping costs one flag read per view
+constexpr int kClipBlocks = 1024;
+
+__global__ __launch_bounds__(256) void rasterize_clip_kernel(const float4 *pos, const SnapRec *snapped, const int32_t *tri, const uint32_t *view_flags,
+                                                             int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, unsigned long long *keys)
+{
+    for (int64_t b = 0; b < batch; ++b) {
+        if (view_flags[b] == 0u) continue;
+        for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_tri; t += int64_t(gridDim.x) * 256)
+            clip_one(pos, snapped, tri, int(b), t, n_vertices, height, width, keys);
+    }
 }
 
 // nvdiffrast's fragment stage: barycentrics from the UNSNAPPED clip-space positions (homogeneous 2-D edge functions),
@@ -465,15 +589,21 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
     if (pixels <= 0) return hipSuccess;
     unsigned long long *keys = static_cast<unsigned long long *>(workspace);
     SnapRec *snapped = reinterpret_cast<SnapRec *>(keys + ((size_t(pixels) + 1) & ~size_t(1)));   // 16-byte aligned
+    uint32_t *view_flags = reinterpret_cast<uint32_t *>(snapped + size_t(batch) * size_t(n_vertices));
     hipError_t e = hipMemsetAsync(keys, 0xFF, size_t(pixels) * sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
     if (batch * n_tri > 0 && batch * n_vertices > 0) {
+        if ((e = hipMemsetAsync(view_flags, 0, size_t(batch) * sizeof(uint32_t), stream)) != hipSuccess) return e;
         hipLaunchKernelGGL(rasterize_snap_kernel, dim3(blocks_for(batch * n_vertices)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip),
-                           batch * n_vertices, double(width), double(height), snapped);
+                           batch * n_vertices, n_vertices, double(width), double(height), snapped, view_flags);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         const int64_t blocks_per_view = (n_tri + 255) / 256;   // (256 = 64 * kWavesPerBlock triangles per workgroup)
         hipLaunchKernelGGL(rasterize_bin_kernel, dim3(unsigned(batch * blocks_per_view)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri,
                            int(blocks_per_view), height, width, keys);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        // triangles that straddle the eye plane (none in a view without a vertex at w <= 0)
+        hipLaunchKernelGGL(rasterize_clip_kernel, dim3(unsigned(std::min<int64_t>(kClipBlocks, blocks_per_view))), dim3(256), 0, stream,
+                           reinterpret_cast<const float4 *>(pos_clip), snapped, tri, view_flags, batch, n_vertices, n_tri, height, width, keys);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,

@@ -14,7 +14,9 @@ installed here: the semantics are a restatement of its published algorithm, pinn
 PARITY UNPINNED against the library itself.
 
 What it does not do, loudly: ``grad_db=True``, ``ranges`` (range mode), ``rast_db`` / ``diff_attrs`` and OpenGL contexts are
-rejected; no polygon clipping (a triangle with a vertex at ``w <= 0`` is dropped); no depth peeling, no texture sampling.
+rejected; clipping is against the NEAR plane only (a triangle with vertices at ``w <= 0`` is clipped there; one with a vertex
+beyond the +-16384-pixel guard band is dropped; the silhouette of a clipped triangle is not antialiased); no depth peeling,
+no texture sampling.
 """
 from __future__ import annotations
 
@@ -54,21 +56,22 @@ def _check_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-# TSSPLAT_AMD_DR_CHECK=1: count, on every rasterize call, the triangles this slice DROPS where nvdiffrast would clip them -- a
-# vertex at w <= 0 (or not finite) or outside the +-16384-pixel guard band -- and warn.  A device read per call: a debugging
-# aid for scenes that may reach the eye plane, off by default (objects inside the frustum, the reference's case, lose nothing).
+# TSSPLAT_AMD_DR_CHECK=1: count, on every rasterize call, the triangles this slice DROPS -- a vertex that is not finite or
+# outside the +-16384-pixel guard band (a finite vertex at w <= 0 is clipped against the near plane, not dropped) -- and warn.
+# A device read per call: a debugging aid, off by default (objects inside the frustum, the reference's case, lose nothing).
 _CHECK_DROPPED = os.environ.get("TSSPLAT_AMD_DR_CHECK", "0") == "1"
 
 
 def count_dropped_triangles(pos: torch.Tensor, tri: torch.Tensor, height: int, width: int) -> int:
-    """(view, triangle) pairs that ``rasterize`` drops whole instead of clipping (see the module docstring)."""
+    """(view, triangle) pairs that ``rasterize`` drops whole (see the module docstring)."""
     with torch.no_grad():
         w = pos[..., 3]
-        ok = torch.isfinite(pos).all(dim=-1) & (w > 0)
-        ws = torch.where(ok, w, torch.ones_like(w))
+        finite = torch.isfinite(pos).all(dim=-1)
+        front = finite & (w > 0)
+        ws = torch.where(front, w, torch.ones_like(w))
         sx = (pos[..., 0] / ws * 0.5 + 0.5) * width
         sy = (pos[..., 1] / ws * 0.5 + 0.5) * height
-        ok &= (sx.abs() <= 16384.0) & (sy.abs() <= 16384.0)
+        ok = (front & (sx.abs() <= 16384.0) & (sy.abs() <= 16384.0)) | (finite & (w <= 0))    # (w <= 0: clipped at the near plane)
         t = tri.long()
         bad = ~(ok[:, t[:, 0]] & ok[:, t[:, 1]] & ok[:, t[:, 2]])
         return int(bad.sum())
@@ -78,8 +81,8 @@ def _warn_dropped(pos, tri, height, width) -> None:
     n = count_dropped_triangles(pos, tri, height, width)
     if n:
         import warnings
-        warnings.warn(f"tssplat_amd.dr.rasterize: {n} (view, triangle) pairs have a vertex at w <= 0 or beyond the +-16384-pixel guard "
-                      f"band and are DROPPED whole (nvdiffrast clips them)", RuntimeWarning, stacklevel=3)
+        warnings.warn(f"tssplat_amd.dr.rasterize: {n} (view, triangle) pairs have a vertex that is not finite or beyond the +-16384-pixel "
+                      f"guard band and are DROPPED whole", RuntimeWarning, stacklevel=3)
 
 
 def _check_tri(tri: torch.Tensor, device) -> torch.Tensor:
@@ -131,8 +134,8 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
     tri = _check_tri(tri, pos.device)
     height, width = int(resolution[0]), int(resolution[1])
     # limits of this slice (include/tssplat_amd.h): the triangle id + 1 travels as a float32 (exact up to 2^24), and window
-    # coordinates are snapped within +-16384 pixels -- a triangle with a vertex beyond that guard band, or at w <= 0, is dropped
-    # whole (nvdiffrast clips): harmless for objects inside the frustum, which is what the reference renders
+    # coordinates are snapped within +-16384 pixels -- a triangle with a vertex beyond that guard band is dropped whole (one with
+    # vertices at w <= 0 is clipped against the near plane): harmless for objects inside the frustum, which the reference renders
     if int(tri.shape[0]) > (1 << 24) - 1:
         raise RuntimeError("tssplat_amd.dr.rasterize: more than 2^24 - 1 triangles")
     if not (0 <= height <= 8192 and 0 <= width <= 8192):
