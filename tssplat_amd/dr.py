@@ -13,8 +13,8 @@ where nvdiffrast is: ``rasterize`` w.r.t. ``pos`` through ``(u, v)``, ``interpol
 installed here: the semantics are a restatement of its published algorithm, pinned down in oracle/raster_oracle.py --
 PARITY UNPINNED against the library itself.
 
-What it does not do, loudly: ``grad_db=True``, ``ranges`` (range mode), ``rast_db`` / ``diff_attrs`` and OpenGL contexts are
-rejected; clipping is against the NEAR plane only (a triangle with vertices at ``w <= 0`` is clipped there; one with a vertex
+What it does not do, loudly: ``grad_db=True``, ``ranges`` (range mode) and ``rast_db`` / ``diff_attrs`` are
+rejected (``RasterizeGLContext`` is an alias of the HIP context); clipping is against the NEAR plane only (a triangle with vertices at ``w <= 0`` is clipped there; one with a vertex
 beyond the +-16384-pixel guard band is dropped; the silhouette of a clipped triangle is not antialiased); no depth peeling,
 no texture sampling.
 """
@@ -46,6 +46,16 @@ class RasterizeCudaContext:
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(max(need, 8), dtype=torch.uint8, device=device)
         return self._ws
+
+
+class RasterizeGLContext(RasterizeCudaContext):
+    """``dr.RasterizeGLContext()`` (mesh_rasterizer.py:35-36, ``context_type == "gl"``).  nvdiffrast's second back end runs the same
+    operators through OpenGL; there is no OpenGL on this platform and nothing in the operators' contract depends on it, so the
+    name is served by the same HIP kernels (``output_db`` / ``mode`` are accepted and ignored: image-space derivatives are not
+    offered by either context here)."""
+
+    def __init__(self, output_db: bool = True, mode: str = "automatic", device=None):
+        super().__init__(device)
 
 
 def _check_cuda_f32(name: str, t: torch.Tensor) -> torch.Tensor:

@@ -5,7 +5,8 @@ caller of SURVEY 8(f) rows 2 and 4: geometry forward (energy + surface gather), 
 Same ``forward`` arguments and output keys (``"shaded"``, ``"geo_regularization"``, ``"n"``, ``"d"``) as the reference, so that
 trainer.py:81-130 reads the same against either.  Host logic only: every tensor operation that is not one of this package's
 kernels is the torch call the reference itself makes (clamp, lerp, masked assignment, norm).  Not mirrored: ``export``
-(xatlas / pymeshlab / cv2, an offline tool), OpenGL contexts, and the reference's structured-config plumbing (the two
+(xatlas / pymeshlab / cv2, an offline tool) and the reference's structured-config plumbing (``context_type="gl"`` is served
+by the same HIP kernels as ``"cuda"``; the two
 ``Config`` fields are keyword arguments).
 """
 from __future__ import annotations
@@ -23,10 +24,10 @@ __all__ = ["MeshRasterizer"]
 class MeshRasterizer(torch.nn.Module):
     def __init__(self, geometry: torch.nn.Module, materials: Optional[torch.nn.Module] = None, context_type: str = "cuda", is_orhto: bool = False):
         super().__init__()
-        if context_type != "cuda":                                   # mesh_rasterizer.py:33-38 ("gl" needs an OpenGL context)
-            raise ValueError("tssplat_amd.renderers.MeshRasterizer: only context_type='cuda' is available")
+        if context_type not in ("cuda", "gl"):                       # mesh_rasterizer.py:33-38
+            raise ValueError("Invalid context type")
         self.is_orhto = bool(is_orhto)                               # (the reference's spelling, mesh_rasterizer.py:24)
-        self.glctx = dr.RasterizeCudaContext()
+        self.glctx = dr.RasterizeCudaContext() if context_type == "cuda" else dr.RasterizeGLContext()   # (both are the HIP kernels)
         self.geometry = geometry
         self.materials = materials
         self.device = geometry.device
