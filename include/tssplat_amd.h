@@ -294,8 +294,12 @@ int tsamd_vertex_normals_backward(const tsamd_surface *s, const float *v_pos_dev
  */
 /* workspace: one 64-bit depth key per pixel, one 16-byte snapped vertex per (view, vertex), one flag per view */
 int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32_t height, int32_t width);
+/* pair_masks_out_dev (OPTIONAL, tsamd_pair_masks_bytes(batch, height, width) bytes): a by-product for tsamd_antialias_prepare --
+ * per 64 consecutive pixels two 64-bit words, bit l = pixel 64 k + l and its right (word 0) / upper (word 1) neighbour show
+ * two different triangles.  The resolve pass has the ids in hand; without it the antialias side reads `rast` back to find them. */
+int64_t tsamd_pair_masks_bytes(int64_t batch, int32_t height, int32_t width);
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles,
-                    int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *stream);
+                    int32_t height, int32_t width, void *workspace_dev, float *rast_out_dev, void *pair_masks_out_dev, void *stream);
 /* A pixel whose id names no triangle of tri_dev (id > n_triangles, e.g. a rast image made with another list) or a triangle
  * with a vertex index outside [0, n_vertices) is treated as background: zero output, zero gradient, nothing read or written
  * out of bounds. */
@@ -330,8 +334,10 @@ int tsamd_rasterize_backward(const float *pos_clip_dev, int64_t batch, int64_t n
 int64_t tsamd_antialias_topology_workspace_bytes(int64_t n_triangles);
 int tsamd_antialias_topology(const int32_t *tri_dev, int64_t n_triangles, void *workspace_dev, int32_t *edge_partner_dev, void *stream);
 int64_t tsamd_antialias_prepared_bytes(int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width);
-int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch,
-                            int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, void *prepared_dev, void *stream);
+/* pair_masks_dev: tsamd_rasterize's by-product for the SAME rast image, or NULL (rast_dev is scanned) */
+int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
+                            const void *pair_masks_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+                            void *prepared_dev, void *stream);
 int tsamd_antialias(const float *color_dev, const float *rast_dev, const float *pos_clip_dev, const void *prepared_dev, const int32_t *tri_dev,
                     const int32_t *edge_partner_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, int32_t n_channels, float *out_dev,
                     void *stream);

@@ -27,9 +27,9 @@ def test_tile_kernels_have_no_static_lds_and_do_not_spill():
     default = [v for k, v in tiles.items() if "ILb1ELi768ELi6ELb0ELb0E" in k]
     assert len(default) == 1 and default[0]["vgpr_count"] <= 80, default      # 6 waves per SIMD: two workgroups per CU
     for name, rec in meta.items():                                          # every kernel of every translation unit
-        if "antialias" in name:
-            # held to 64 VGPRs on purpose: the float64 silhouette analysis spills, the 99 % of lanes that only compare two ids
-            # run at eight waves per SIMD (aa_kernels.hip)
+        if "antialias" in name and "masked" not in name:
+            # the table-free antialias kernels are held to 64 VGPRs on purpose: the float64 silhouette analysis spills, the lanes
+            # that only compare two ids run at eight waves per SIMD; the masked kernels (no lane per pixel) spill nothing
             assert rec["vgpr_count"] <= 64 and rec["private_segment_fixed_size"] <= 256, (name, rec)
             continue
         assert rec["vgpr_spill_count"] == 0 and rec["private_segment_fixed_size"] == 0, (name, rec)

@@ -158,18 +158,18 @@ def test_c_abi_rejects_bad_arguments():
     lib = _capi.load()
     assert lib.tsamd_rasterize_workspace_bytes(8, 1000, 512, 512) == 8 * 512 * 512 * 8 + 8 * 1000 * 16 + 32      # keys, snapped vertices, view flags
     assert lib.tsamd_rasterize_workspace_bytes(-1, 3, 4, 4) == -1
-    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None) == 1          # null workspace / output
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 4, 4, None, None, None, None) == 1          # null workspace / output
     assert b"null" in lib.tsamd_last_error()
-    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 20000, 4, None, None, None) == 1
-    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 9000, 4, None, None, None) == 1       # beyond the 8192-pixel guard-band limit
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 20000, 4, None, None, None, None) == 1
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1, 9000, 4, None, None, None, None) == 1       # beyond the 8192-pixel guard-band limit
     assert b"8192" in lib.tsamd_last_error()
-    assert lib.tsamd_rasterize(None, 1, 3, None, 1 << 24, 4, 4, None, None, None) == 1    # ids travel as float32: <= 2^24 - 1 triangles
+    assert lib.tsamd_rasterize(None, 1, 3, None, 1 << 24, 4, 4, None, None, None, None) == 1    # ids travel as float32: <= 2^24 - 1 triangles
     assert b"2^24" in lib.tsamd_last_error()
     assert lib.tsamd_interpolate(None, 2, 3, 3, None, None, 1, 4, 4, 4, None, None) == 1     # attr_batch neither 1 nor batch
     assert lib.tsamd_interpolate(None, 1, 3, 3, None, None, -1, 1, 4, 4, None, None) == 1    # negative triangle count
     assert lib.tsamd_interpolate_backward(None, 1, 3, 0, None, None, 1, 1, 4, 4, None, None, None, None) == 1
     # empty images are fine without any pointer
-    assert lib.tsamd_rasterize(None, 0, 0, None, 0, 0, 0, None, None, None) == 0
+    assert lib.tsamd_rasterize(None, 0, 0, None, 0, 0, 0, None, None, None, None) == 0
 
 
 def _octasphere(levels=2, radius=0.7):
@@ -291,8 +291,8 @@ def test_c_abi_checks_antialias_arguments():
     assert lib.tsamd_antialias_backward(None, None, None, None, None, None, 0, 0, 0, 0, 0, 1, None, 1.0, None, None, None) == 1   # no output asked for
     assert lib.tsamd_antialias_prepared_bytes(2, 5, 7, 4, 8) == 3 * 256                                       # windows | pair masks | edge flags, each padded
     assert lib.tsamd_antialias_prepared_bytes(-1, 5, 7, 4, 8) == -1
-    assert lib.tsamd_antialias_prepare(None, None, None, None, 1, 3, 1, 4, 4, None, None) == 1                # null buffers
-    assert lib.tsamd_antialias_prepare(None, None, None, None, 0, 0, 0, 4, 4, None, None) == 0                # nothing to do
+    assert lib.tsamd_antialias_prepare(None, None, None, None, None, 1, 3, 1, 4, 4, None, None) == 1                # null buffers
+    assert lib.tsamd_antialias_prepare(None, None, None, None, None, 0, 0, 0, 4, 4, None, None) == 0                # nothing to do
     assert lib.tsamd_rasterize_backward(None, 1, 3, None, 1, 4, 4, None, None, None, None) == 1
     assert b"null" in lib.tsamd_last_error()
 
@@ -437,6 +437,7 @@ def test_antialias_forward_backward(kind, spheres, views, res, channels, prepare
     import torch
     import tssplat_amd.dr as dr
     monkeypatch.setattr(dr, "PREPARE_ANTIALIAS", prepare)      # both forms of the analysis (tables per view / everything per pixel pair)
+    monkeypatch.setattr(dr, "PAIR_MASKS_FROM_RASTERIZE", channels == 1)   # pair masks from the resolve pass / from a scan of rast
     pos_clip, tri, _ = _surface_scene(kind, spheres, views)
     ctx = dr.RasterizeCudaContext()
     tri_d = torch.from_numpy(tri).cuda()
@@ -573,6 +574,54 @@ def test_interpolate_bounds_on_foreign_rast():
     empty = torch.zeros((0, 3), dtype=torch.int32, device="cuda")
     out0, _ = dr.interpolate(attr.detach(), rast.detach(), empty)
     assert float(out0.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [(64, 64), (50, 128), (33, 20), (7, 192), (128, 96)])
+def test_pair_masks_of_the_resolve_pass_equal_a_scan_of_rast(res):
+    """tsamd_rasterize's optional by-product (which pixels differ from their right / upper neighbour, 2 bits per pixel) against
+    antialias_detect_kernel's scan of the finished image: tiled (width % 64 == 0, also with a ragged last row group) and
+    flat resolve kernels."""
+    import torch
+    from tssplat_amd import _capi
+    lib = _capi.load()
+    H, W = res
+    pos_clip, tri, _ = _surface_scene("kuhn8", 4, 3)
+    B, V, T = pos_clip.shape[0], pos_clip.shape[1], tri.shape[0]
+    pos = torch.from_numpy(pos_clip).cuda()
+    tri_d = torch.from_numpy(tri).cuda()
+    ws = torch.empty(int(lib.tsamd_rasterize_workspace_bytes(B, V, H, W)), dtype=torch.uint8, device="cuda")
+    rast = torch.empty((B, H, W, 4), device="cuda")
+    nm = int(lib.tsamd_pair_masks_bytes(B, H, W))
+    assert nm == (B * H * W + 63) // 64 * 16
+    masks = torch.full((nm,), 0xAB, dtype=torch.uint8, device="cuda")
+    _capi.check(lib.tsamd_rasterize(pos.data_ptr(), B, V, tri_d.data_ptr(), T, H, W, ws.data_ptr(), rast.data_ptr(), masks.data_ptr(), None))
+    rast2 = torch.empty_like(rast)
+    _capi.check(lib.tsamd_rasterize(pos.data_ptr(), B, V, tri_d.data_ptr(), T, H, W, ws.data_ptr(), rast2.data_ptr(), None, None))
+    assert torch.equal(rast, rast2)
+    opp = torch.empty(3 * T, dtype=torch.int32, device="cuda")
+    tws = torch.empty(int(lib.tsamd_antialias_topology_workspace_bytes(T)), dtype=torch.uint8, device="cuda")
+    _capi.check(lib.tsamd_antialias_topology(tri_d.data_ptr(), T, tws.data_ptr(), opp.data_ptr(), None))
+    n = int(lib.tsamd_antialias_prepared_bytes(B, V, T, H, W))
+    scanned, handed = (torch.zeros(n, dtype=torch.uint8, device="cuda") for _ in range(2))
+    _capi.check(lib.tsamd_antialias_prepare(rast.data_ptr(), pos.data_ptr(), tri_d.data_ptr(), opp.data_ptr(), None, B, V, T, H, W, scanned.data_ptr(), None))
+    _capi.check(lib.tsamd_antialias_prepare(rast.data_ptr(), pos.data_ptr(), tri_d.data_ptr(), opp.data_ptr(), masks.data_ptr(), B, V, T, H, W,
+                                            handed.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(scanned, handed)
+    off = (B * V * 16 + 255) // 256 * 256                         # (the masks sit behind the window table)
+    m = scanned[off:off + nm].cpu().numpy().view(np.uint64).reshape(-1, 2)
+    assert torch.equal(masks, scanned[off:off + nm]) and m.any()
+    # and against numpy on the image itself
+    ids = rast[..., 3].cpu().numpy().reshape(B, H, W)
+    c0 = np.zeros((B, H, W), bool)
+    c1 = np.zeros((B, H, W), bool)
+    c0[:, :, :-1] = ids[:, :, 1:] != ids[:, :, :-1]
+    c1[:, :-1, :] = ids[:, 1:, :] != ids[:, :-1, :]
+    bits = np.zeros((m.shape[0] * 64, 2), bool)
+    bits[:B * H * W, 0], bits[:B * H * W, 1] = c0.reshape(-1), c1.reshape(-1)
+    want = (bits.reshape(-1, 64, 2).astype(np.uint64) << np.arange(64, dtype=np.uint64)[None, :, None]).sum(axis=1, dtype=np.uint64)
+    assert np.array_equal(m, want)
 
 
 @pytest.mark.gpu

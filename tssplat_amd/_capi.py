@@ -131,8 +131,9 @@ SIGNATURES = {
     "tsamd_train_loop_destroy": (None, [C.c_void_p]),
     # renderer slice
     "tsamd_rasterize_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    "tsamd_pair_masks_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "tsamd_rasterize": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
-                                  C.c_void_p]),
+                                  C.c_void_p, C.c_void_p]),
     "tsamd_interpolate": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p]),
     "tsamd_interpolate_backward": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
@@ -142,8 +143,8 @@ SIGNATURES = {
     "tsamd_antialias_topology_workspace_bytes": (C.c_int64, [C.c_int64]),
     "tsamd_antialias_topology": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsamd_antialias_prepared_bytes": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
-    "tsamd_antialias_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
-                                          C.c_void_p, C.c_void_p]),
+    "tsamd_antialias_prepare": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                          C.c_int32, C.c_void_p, C.c_void_p]),
     "tsamd_antialias": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "tsamd_antialias_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,

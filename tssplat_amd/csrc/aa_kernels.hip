@@ -295,24 +295,17 @@ __global__ __launch_bounds__(kAaBlock) void antialias_detect_kernel(const float4
     }
 }
 
-// the workgroup's pairs, compacted into L; returns their number.  PREPARED: from the masks, else from `rast`.
-template <bool PREPARED>
-__device__ __forceinline__ int collect_pairs(const float4 *rast, const unsigned long long *masks, int64_t first_pixel, int64_t total, int64_t hw, int height,
-                                             int width, PairList &L)
+// ---- drivers: call work(pixel, axis) for every pair of an image, lanes filled densely ----
+//
+// Without tables (prepared_dev = NULL): one workgroup per 256 consecutive pixels, detect + compaction in LDS, two barriers.
+template <class Work>
+__device__ __forceinline__ void for_pairs_detected(const float4 *rast, int64_t total, int64_t hw, int height, int width, PairList &L, Work &&work)
 {
-    const int64_t gid = first_pixel + threadIdx.x;
+    const int64_t first_pixel = int64_t(blockIdx.x) * kAaBlock;
     if (threadIdx.x == 0) L.count = 0;
     __syncthreads();
     bool c[2];
-    if (PREPARED) {
-        const int64_t chunk = (first_pixel >> 6) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));   // (one 64-pixel chunk per wave: scalar loads)
-        const bool have = (chunk << 6) < total;
-        const unsigned long long m0 = have ? masks[2 * chunk] : 0ull, m1 = have ? masks[2 * chunk + 1] : 0ull;
-        c[0] = (m0 >> (threadIdx.x & 63)) & 1ull;
-        c[1] = (m1 >> (threadIdx.x & 63)) & 1ull;
-    } else {
-        differing_neighbours(rast, gid, total, hw, height, width, c);
-    }
+    differing_neighbours(rast, first_pixel + threadIdx.x, total, hw, height, width, c);
 #pragma unroll
     for (int axis = 0; axis < 2; ++axis) {
         const unsigned long long mask = __ballot(c[axis]);
@@ -323,52 +316,108 @@ __device__ __forceinline__ int collect_pairs(const float4 *rast, const unsigned 
         if (c[axis]) L.items[base + int(__builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)))] = (threadIdx.x << 1) | uint32_t(axis);
     }
     __syncthreads();
-    return L.count;
-}
-
-// Occupancy: the float64 analysis wants 100 (forward) / 130 (backward) VGPRs, but the detect phase is all that ~2/3 of the
-// workgroups ever run and its speed is the occupancy the register count leaves.  Both kernels are held to 64 VGPRs = 8 waves per
-// SIMD and the analysis spills (scratch touched by the analysing lanes only).
-template <bool TABLE>
-__global__ __launch_bounds__(kAaBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_kernel(const float *color, const float4 *rast, const float4 *pos, const double2 *windows, const unsigned long long *masks, const uint8_t *flags, const int32_t *tri, const int32_t *opp,
-                                                        int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, int channels, float *out)
-{
-    __shared__ PairList L;
-    const int64_t hw = int64_t(height) * width;
-    const int64_t first_pixel = int64_t(blockIdx.x) * kAaBlock;
-    const int n = collect_pairs<TABLE>(rast, masks, first_pixel, batch * hw, hw, height, width, L);
+    const int n = L.count;
     for (int k = threadIdx.x; k < n; k += kAaBlock) {
         const uint32_t item = L.items[k];
-        const int64_t gid = first_pixel + (item >> 1);
+        work(first_pixel + (item >> 1), int(item & 1u));
+    }
+}
+
+// With the pair masks of tsamd_antialias_prepare: no lane per pixel at all.  A wave takes `group` (<= 64) consecutive 64-pixel
+// chunks, lane l loads the two mask words of chunk l, and the wave walks the chunks that have a pair (most have none and cost
+// nothing beyond that one coalesced load): a chunk's pairs are pushed on a small per-wave stack in LDS (position from the mask's
+// bit count, no atomic), and whenever the stack holds 64 they are analysed, one pair per lane -- full waves in the float64
+// analysis whatever the image looks like, no barrier, no workgroup-wide step.
+constexpr int kPairStack = 192;   // < 64 left over + at most 128 pushed per chunk
+
+__device__ __forceinline__ unsigned long long read_lane_u64(unsigned long long v, int lane)
+{
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v)), lane)), hi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(v >> 32)), lane));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <class Work>
+__device__ __forceinline__ void for_pairs_masked(const unsigned long long *masks, int64_t n_chunks, int group, uint16_t *stack, Work &&work)
+{
+    const int lane = int(threadIdx.x) & 63;
+    const int64_t chunk0 = (int64_t(blockIdx.x) * (kAaBlock / 64) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * group;
+    if (chunk0 >= n_chunks) return;
+    unsigned long long m0 = 0ull, m1 = 0ull;
+    if (lane < group && chunk0 + lane < n_chunks) {
+        m0 = masks[2 * (chunk0 + lane)];
+        m1 = masks[2 * (chunk0 + lane) + 1];
+    }
+    unsigned long long todo = __ballot((m0 | m1) != 0ull);
+    int count = 0;   // wave-uniform
+    for (;;) {
+        while (count < 64 && todo != 0ull) {   // push the pairs of the next chunk that has any
+            const int c = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+            todo &= todo - 1ull;
+#pragma unroll
+            for (int axis = 0; axis < 2; ++axis) {
+                const unsigned long long m = read_lane_u64(axis ? m1 : m0, c);
+                if ((m >> lane) & 1ull)
+                    stack[count + int(__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)))] = uint16_t((c << 7) | (lane << 1) | axis);
+                count += __popcll(m);
+            }
+        }
+        if (count == 0) break;
+        const int n = min(count, 64);   // the top of the stack: a full wave of pairs except at the very end
+        count -= n;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < n) {
+            const uint32_t item = stack[count + lane];
+            work((chunk0 + (item >> 7)) * 64 + ((item >> 1) & 63u), int(item & 1u));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// chunks per wave of the masked form: enough waves to fill the chip (>= ~16 k) before a wave takes more than one chunk
+int masked_group(int64_t n_chunks)
+{
+    int g = 1;
+    while (g < 64 && n_chunks / (2 * g) >= 16384) g *= 2;
+    return g;
+}
+
+template <bool TABLE>
+__device__ __forceinline__ void antialias_body(const float *color, const float4 *rast, const float4 *pos, const double2 *windows, const unsigned long long *masks, const uint8_t *flags, const int32_t *tri, const int32_t *opp,
+                                                        int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, int channels, int group, float *out)
+{
+    const int64_t hw = int64_t(height) * width;
+    auto work = [&](int64_t gid, int axis) {
         const int64_t b = gid / hw, pix = gid - b * hw;
         const int j = int(pix / width), i = int(pix - int64_t(j) * width);
         const float *cv = color + b * hw * channels;
         float *ov = out + b * hw * channels;
-        pair_blends<TABLE>(rast + b * hw, pos + b * n_vertices, TABLE ? windows + b * n_vertices : nullptr, TABLE ? flags + b * n_tri : nullptr, tri, opp, n_vertices, n_tri, height, width, j, i, int(item & 1u), [&](const Blend &e) {
+        pair_blends<TABLE>(rast + b * hw, pos + b * n_vertices, TABLE ? windows + b * n_vertices : nullptr, TABLE ? flags + b * n_tri : nullptr, tri, opp, n_vertices, n_tri, height, width, j, i, axis, [&](const Blend &e) {
             for (int c = 0; c < channels; ++c) atomicAdd(ov + e.dst * channels + c, e.weight * (cv[e.src * channels + c] - cv[e.dst * channels + c]));
         });
+    };
+    if (TABLE) {
+        __shared__ uint16_t stacks[(kAaBlock / 64) * kPairStack];
+        for_pairs_masked(masks, (batch * hw + 63) / 64, group, stacks + (threadIdx.x >> 6) * kPairStack, work);
+    } else {
+        __shared__ PairList L;
+        for_pairs_detected(rast, batch * hw, hw, height, width, L, work);
     }
 }
 
 template <bool TABLE>
-__global__ __launch_bounds__(kAaBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_backward_kernel(const float *color, const float4 *rast, const float4 *pos, const double2 *windows, const unsigned long long *masks, const uint8_t *flags, const int32_t *tri,
+__device__ __forceinline__ void antialias_backward_body(const float *color, const float4 *rast, const float4 *pos, const double2 *windows, const unsigned long long *masks, const uint8_t *flags, const int32_t *tri,
                                                                  const int32_t *opp, int64_t batch, int64_t n_vertices, int64_t n_tri, int height,
-                                                                 int width, int channels, const float *grad_out, float boost, float *grad_color,
+                                                                 int width, int channels, int group, const float *grad_out, float boost, float *grad_color,
                                                                  float4 *grad_pos)
 {
-    __shared__ PairList L;
     const int64_t hw = int64_t(height) * width;
-    const int64_t first_pixel = int64_t(blockIdx.x) * kAaBlock;
-    const int n = collect_pairs<TABLE>(rast, masks, first_pixel, batch * hw, hw, height, width, L);
-    for (int k = threadIdx.x; k < n; k += kAaBlock) {
-        const uint32_t item = L.items[k];
-        const int64_t gid = first_pixel + (item >> 1);
+    auto work = [&](int64_t gid, int axis) {
         const int64_t b = gid / hw, pix = gid - b * hw;
         const int j = int(pix / width), i = int(pix - int64_t(j) * width);
         const float *cv = color + b * hw * channels;
         const float *gv = grad_out + b * hw * channels;
         const float4 *pv = pos + b * n_vertices;
-        pair_blends<TABLE>(rast + b * hw, pv, TABLE ? windows + b * n_vertices : nullptr, TABLE ? flags + b * n_tri : nullptr, tri, opp, n_vertices, n_tri, height, width, j, i, int(item & 1u), [&](const Blend &e) {
+        pair_blends<TABLE>(rast + b * hw, pv, TABLE ? windows + b * n_vertices : nullptr, TABLE ? flags + b * n_tri : nullptr, tri, opp, n_vertices, n_tri, height, width, j, i, axis, [&](const Blend &e) {
             float dot = 0.f;
             for (int c = 0; c < channels; ++c) {
                 const float g = gv[e.dst * channels + c];
@@ -395,7 +444,38 @@ __global__ __launch_bounds__(kAaBlock) __attribute__((amdgpu_waves_per_eu(8, 8))
                 }
             }
         });
+    };
+    if (TABLE) {
+        __shared__ uint16_t stacks[(kAaBlock / 64) * kPairStack];
+        for_pairs_masked(masks, (batch * hw + 63) / 64, group, stacks + (threadIdx.x >> 6) * kPairStack, work);
+    } else {
+        __shared__ PairList L;
+        for_pairs_detected(rast, batch * hw, hw, height, width, L, work);
     }
+}
+
+// The table-free kernels have a lane per pixel in their detect phase and are held to 64 VGPRs (8 waves per SIMD; the analysis
+// spills a little); the masked kernels have no such phase -- few waves, all of them in the analysis -- and take the registers
+// the analysis wants.
+#define TSAMD_AA_ARGS                                                                                                                       \
+    const float *color, const float4 *rast, const float4 *pos, const double2 *windows, const unsigned long long *masks, const uint8_t *flags, \
+        const int32_t *tri, const int32_t *opp, int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, int channels, int group
+#define TSAMD_AA_PASS color, rast, pos, windows, masks, flags, tri, opp, batch, n_vertices, n_tri, height, width, channels, group
+
+__global__ __launch_bounds__(kAaBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_kernel(TSAMD_AA_ARGS, float *out)
+{
+    antialias_body<false>(TSAMD_AA_PASS, out);
+}
+__global__ __launch_bounds__(kAaBlock) void antialias_masked_kernel(TSAMD_AA_ARGS, float *out) { antialias_body<true>(TSAMD_AA_PASS, out); }
+
+__global__ __launch_bounds__(kAaBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void antialias_backward_kernel(TSAMD_AA_ARGS, const float *grad_out, float boost,
+                                                                                                                float *grad_color, float4 *grad_pos)
+{
+    antialias_backward_body<false>(TSAMD_AA_PASS, grad_out, boost, grad_color, grad_pos);
+}
+__global__ __launch_bounds__(kAaBlock) void antialias_backward_masked_kernel(TSAMD_AA_ARGS, const float *grad_out, float boost, float *grad_color, float4 *grad_pos)
+{
+    antialias_backward_body<true>(TSAMD_AA_PASS, grad_out, boost, grad_color, grad_pos);
 }
 
 unsigned blocks_for(int64_t n) { return unsigned((n + 255) / 256); }
@@ -449,13 +529,15 @@ static Prepared prepared_layout(int64_t batch, int64_t n_vertices, int64_t n_tri
     return p;
 }
 
+int64_t pair_masks_bytes(int64_t batch, int height, int width) { return (batch * int64_t(height) * width + 63) / 64 * 16; }
+
 int64_t antialias_prepared_bytes(int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width)
 {
     return prepared_layout(batch, n_vertices, n_tri, height, width).bytes;
 }
 
-hipError_t launch_antialias_prepare(const float *rast, const float *pos_clip, const int32_t *tri, const int32_t *opp, int64_t batch, int64_t n_vertices,
-                                    int64_t n_tri, int height, int width, void *prepared, hipStream_t stream)
+hipError_t launch_antialias_prepare(const float *rast, const float *pos_clip, const int32_t *tri, const int32_t *opp, const void *pair_masks, int64_t batch,
+                                    int64_t n_vertices, int64_t n_tri, int height, int width, void *prepared, hipStream_t stream)
 {
     const int64_t n = batch * n_vertices, pixels = batch * int64_t(height) * width;
     const Prepared lay = prepared_layout(batch, n_vertices, n_tri, height, width);
@@ -472,6 +554,8 @@ hipError_t launch_antialias_prepare(const float *rast, const float *pos_clip, co
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (pixels <= 0) return hipSuccess;
+    if (pair_masks)   // the rasteriser found them while it resolved the image
+        return hipMemcpyAsync(base + lay.masks, pair_masks, size_t(pair_masks_bytes(batch, height, width)), hipMemcpyDeviceToDevice, stream);
     hipLaunchKernelGGL(antialias_detect_kernel, dim3(blocks_for(pixels)), dim3(kAaBlock), 0, stream, reinterpret_cast<const float4 *>(rast), pixels,
                        int64_t(height) * width, height, width, reinterpret_cast<unsigned long long *>(base + lay.masks));
     return hipGetLastError();
@@ -488,9 +572,11 @@ hipError_t launch_antialias(const float *color, const float *rast, const float *
     const Prepared lay = prepared_layout(batch, n_vertices, n_tri, height, width);
     const unsigned long long *masks = prepared ? reinterpret_cast<const unsigned long long *>(static_cast<const char *>(prepared) + lay.masks) : nullptr;
     const uint8_t *flags = prepared ? reinterpret_cast<const uint8_t *>(static_cast<const char *>(prepared) + lay.flags) : nullptr;
-    hipLaunchKernelGGL(prepared ? antialias_kernel<true> : antialias_kernel<false>, dim3(blocks_for(pixels)), dim3(kAaBlock), 0, stream, color, reinterpret_cast<const float4 *>(rast),
+    const int group = masked_group((pixels + 63) / 64);
+    const int64_t masked_waves = ((pixels + 63) / 64 + group - 1) / group;
+    hipLaunchKernelGGL(prepared ? antialias_masked_kernel : antialias_kernel, dim3(prepared ? blocks_for(masked_waves * 64) : blocks_for(pixels)), dim3(kAaBlock), 0, stream, color, reinterpret_cast<const float4 *>(rast),
                        reinterpret_cast<const float4 *>(pos_clip), static_cast<const double2 *>(prepared), masks, flags, tri, opp, batch, n_vertices, n_tri, height, width,
-                       channels, out);
+                       channels, group, out);
     return hipGetLastError();
 }
 
@@ -512,9 +598,11 @@ hipError_t launch_antialias_backward(const float *color, const float *rast, cons
     const Prepared lay = prepared_layout(batch, n_vertices, n_tri, height, width);
     const unsigned long long *masks = prepared ? reinterpret_cast<const unsigned long long *>(static_cast<const char *>(prepared) + lay.masks) : nullptr;
     const uint8_t *flags = prepared ? reinterpret_cast<const uint8_t *>(static_cast<const char *>(prepared) + lay.flags) : nullptr;
-    hipLaunchKernelGGL(prepared ? antialias_backward_kernel<true> : antialias_backward_kernel<false>, dim3(blocks_for(pixels)), dim3(kAaBlock), 0, stream, color, reinterpret_cast<const float4 *>(rast),
+    const int group = masked_group((pixels + 63) / 64);
+    const int64_t masked_waves = ((pixels + 63) / 64 + group - 1) / group;
+    hipLaunchKernelGGL(prepared ? antialias_backward_masked_kernel : antialias_backward_kernel, dim3(prepared ? blocks_for(masked_waves * 64) : blocks_for(pixels)), dim3(kAaBlock), 0, stream, color, reinterpret_cast<const float4 *>(rast),
                        reinterpret_cast<const float4 *>(pos_clip), static_cast<const double2 *>(prepared), masks, flags, tri, opp, batch, n_vertices, n_tri, height, width,
-                       channels, grad_out, boost, grad_color,
+                       channels, group, grad_out, boost, grad_color,
                        reinterpret_cast<float4 *>(grad_pos));
     return hipGetLastError();
 }

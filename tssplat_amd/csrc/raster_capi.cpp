@@ -30,8 +30,14 @@ int64_t tsamd_rasterize_workspace_bytes(int64_t batch, int64_t n_vertices, int32
     return ((batch * int64_t(height) * int64_t(width) + 1) & ~int64_t(1)) * 8 + batch * n_vertices * 16 + ((batch * 4 + 15) & ~int64_t(15));
 }
 
+int64_t tsamd_pair_masks_bytes(int64_t batch, int32_t height, int32_t width)
+{
+    if (check_image(batch, height, width) != TSAMD_OK) return -1;
+    return tsamd::pair_masks_bytes(batch, height, width);
+}
+
 int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices, const int32_t *tri_dev, int64_t n_triangles, int32_t height,
-                    int32_t width, void *workspace_dev, float *rast_out_dev, void *stream)
+                    int32_t width, void *workspace_dev, float *rast_out_dev, void *pair_masks_out_dev, void *stream)
 {
     int rc = check_image(batch, height, width);
     if (rc) return rc;
@@ -43,7 +49,7 @@ int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices
     if (pixels > 0 && (!workspace_dev || !rast_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "workspace_dev / rast_out_dev is null");
     if (batch * n_triangles > 0 && (!pos_clip_dev || !tri_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "pos_clip_dev / tri_dev is null");
     TSAMD_HIP(tsamd::launch_rasterize(pos_clip_dev, batch, n_vertices, tri_dev, n_triangles, height, width, workspace_dev, rast_out_dev,
-                                      static_cast<hipStream_t>(stream)));
+                                      pair_masks_out_dev, static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }
 
@@ -124,17 +130,19 @@ int64_t tsamd_antialias_prepared_bytes(int64_t batch, int64_t n_vertices, int64_
     return tsamd::antialias_prepared_bytes(batch, n_vertices, n_triangles, height, width);
 }
 
-int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev, int64_t batch,
-                            int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width, void *prepared_dev, void *stream)
+int tsamd_antialias_prepare(const float *rast_dev, const float *pos_clip_dev, const int32_t *tri_dev, const int32_t *edge_partner_dev,
+                            const void *pair_masks_dev, int64_t batch, int64_t n_vertices, int64_t n_triangles, int32_t height, int32_t width,
+                            void *prepared_dev, void *stream)
 {
     int rc = check_antialias(batch, n_vertices, n_triangles, height, width, 1);
     if (rc) return rc;
     const int64_t pixels = batch * int64_t(height) * width;
     if ((pixels > 0 || batch * n_vertices > 0) && !prepared_dev) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "prepared_dev is null");
-    if ((pixels > 0 && !rast_dev) || (batch * n_vertices > 0 && !pos_clip_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "rast_dev / pos_clip_dev is null");
+    if ((pixels > 0 && !rast_dev && !pair_masks_dev) || (batch * n_vertices > 0 && !pos_clip_dev))
+        return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "rast_dev (without pair_masks_dev) / pos_clip_dev is null");
     if (batch * n_triangles > 0 && (!tri_dev || !edge_partner_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "tri_dev / edge_partner_dev is null");
-    TSAMD_HIP(tsamd::launch_antialias_prepare(rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, batch, n_vertices, n_triangles, height, width, prepared_dev,
-                                              static_cast<hipStream_t>(stream)));
+    TSAMD_HIP(tsamd::launch_antialias_prepare(rast_dev, pos_clip_dev, tri_dev, edge_partner_dev, pair_masks_dev, batch, n_vertices, n_triangles, height, width,
+                                              prepared_dev, static_cast<hipStream_t>(stream)));
     return TSAMD_OK;
 }
 

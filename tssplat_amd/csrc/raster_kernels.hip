@@ -361,28 +361,70 @@ constexpr int kClipBlocks = 1024;
 __global__ __launch_bounds__(256) void rasterize_clip_kernel(const float4 *pos, const SnapRec *snapped, const int32_t *tri, const uint32_t *view_flags,
                                                              int64_t batch, int64_t n_vertices, int64_t n_tri, int height, int width, unsigned long long *keys)
 {
-    for (int64_t b = 0; b < batch; ++b) {
-        if (view_flags[b] == 0u) continue;
-        for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_tri; t += int64_t(gridDim.x) * 256)
-            clip_one(pos, snapped, tri, int(b), t, n_vertices, height, width, keys);
+    const int lane = int(threadIdx.x) & 63;
+    for (int64_t base = 0; base < batch; base += 64) {   // the flags of 64 views in one load; only flagged views are visited
+        unsigned long long flagged = __ballot(base + lane < batch && view_flags[base + lane] != 0u);
+        while (flagged != 0ull) {
+            const int64_t b = base + __builtin_amdgcn_readfirstlane(__ffsll((long long)flagged) - 1);
+            flagged &= flagged - 1ull;
+            for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_tri; t += int64_t(gridDim.x) * 256)
+                clip_one(pos, snapped, tri, int(b), t, n_vertices, height, width, keys);
+        }
     }
 }
 
-// nvdiffrast's fragment stage: barycentrics from the UNSNAPPED clip-space positions (homogeneous 2-D edge functions),
-// perspective-correct by construction; oracle/raster_oracle.py::resolve in float32.
+// A wave holds 64 consecutive pixels of the flattened [view, row, column] image -- what the pair masks are indexed by, and the
+// order in which keys are read and `rast` is written as one stream.  (Four rows x 64 columns per workgroup, the upper neighbour
+// handed over in LDS, was tried: the strided streams alone cost 138 -> 172 us on 120 views x 512^2.)
 __global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t batch,
-                                                                int height, int width, const unsigned long long *keys, float4 *rast)
+                                                                int height, int width, const unsigned long long *keys, float4 *rast,
+                                                                unsigned long long *pair_masks)
 {
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t hw = int64_t(height) * width;
-    if (gid >= batch * hw) return;
-    const unsigned long long key = keys[gid];
+    const int lane = int(threadIdx.x) & 63;
+    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const bool have = gid < batch * hw;
+    // view / row / column without a per-lane 64-bit division: the view of the wave's first pixel on the scalar unit (a wave crosses
+    // at most one view boundary unless the image has fewer than 64 pixels)
+    int64_t b;
+    uint32_t pix;
+    if (hw >= 64) {
+        const int64_t gid0 = int64_t(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(int(threadIdx.x & ~63u));
+        const int64_t b0 = gid0 / hw;
+        const int64_t off = gid - b0 * hw;
+        b = off >= hw ? b0 + 1 : b0;
+        pix = uint32_t(off >= hw ? off - hw : off);
+    } else {
+        b = gid / hw;
+        pix = uint32_t(gid - b * hw);
+    }
+    const int py = int(pix / uint32_t(width)), px = int(pix - uint32_t(py) * uint32_t(width));   // (pix < 2^26: height, width <= 8192)
+    // all global loads first, together: the kernel is bound by the latency of its key loads (a second round trip behind the first
+    // costs as much again)
+    const bool want_right = pair_masks && have && px + 1 < width && lane == 63;   // (the other lanes ask their neighbour lane)
+    const bool want_up = pair_masks && have && py + 1 < height;
+    const unsigned long long key = have ? keys[gid] : kNoFragment;
+    const unsigned long long key_right = want_right ? keys[gid + 1] : 0ull, key_up = want_up ? keys[gid + width] : 0ull;
+    if (pair_masks) {
+        // by-product for tsamd_antialias_prepare: does the pixel's triangle differ from its right / upper neighbour's?  Two 64-bit
+        // words per 64 pixels (this wave), what antialias_detect_kernel would otherwise find by reading the whole `rast` image back.
+        const uint32_t id = uint32_t(key);
+        const uint32_t next = uint32_t(__shfl_down(int(id), 1));   // (every lane takes part: lane 62 reads lane 63)
+        const uint32_t right = lane == 63 ? (want_right ? uint32_t(key_right) : id) : next;
+        const uint32_t up = want_up ? uint32_t(key_up) : id;
+        const bool c0 = have && px + 1 < width && right != id;
+        const bool c1 = have && py + 1 < height && up != id;
+        const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+        if (lane == 0 && have) {
+            pair_masks[2 * (gid >> 6)] = m0;
+            pair_masks[2 * (gid >> 6) + 1] = m1;
+        }
+    }
+    if (!have) return;
     if (key == kNoFragment) {
         rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const int64_t b = gid / hw, pix = gid - b * hw;
-    const int py = int(pix / width), px = int(pix - int64_t(py) * width);
     const int64_t t = int64_t(key & 0xFFFFFFFFull);
     const float4 *pv = pos + b * n_vertices;
     const float4 v0 = pv[tri[3 * t]], v1 = pv[tri[3 * t + 1]], v2 = pv[tri[3 * t + 2]];
@@ -583,7 +625,7 @@ unsigned blocks_for(int64_t n) { return unsigned((n + 255) / 256); }
 }  // namespace
 
 hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vertices, const int32_t *tri, int64_t n_tri, int height, int width,
-                            void *workspace, float *rast, hipStream_t stream)
+                            void *workspace, float *rast, void *pair_masks, hipStream_t stream)
 {
     const int64_t pixels = batch * int64_t(height) * width;
     if (pixels <= 0) return hipSuccess;
@@ -607,7 +649,7 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
-                       n_vertices, batch, height, width, keys, reinterpret_cast<float4 *>(rast));
+                       n_vertices, batch, height, width, keys, reinterpret_cast<float4 *>(rast), static_cast<unsigned long long *>(pair_masks));
     return hipGetLastError();
 }
 

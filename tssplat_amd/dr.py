@@ -109,13 +109,13 @@ class _RasterizeFunc(torch.autograd.Function):
     """``rast`` with the gradient of its ``(u, v)`` channels w.r.t. ``pos`` (tsamd_rasterize_backward)."""
 
     @staticmethod
-    def forward(ctx, pos, tri, glctx, height, width):
+    def forward(ctx, pos, tri, glctx, height, width, pair_masks):
         B, V = int(pos.shape[0]), int(pos.shape[1])
         rast = torch.empty((B, height, width, 4), dtype=torch.float32, device=pos.device)
         ws = glctx.workspace(B, V, height, width, pos.device)
         with _device_ctx(pos.device):
             _capi.check(_lib.tsamd_rasterize(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), height, width, ws.data_ptr(),
-                                             rast.data_ptr(), _stream_ptr(pos.device)))
+                                             rast.data_ptr(), None if pair_masks is None else pair_masks.data_ptr(), _stream_ptr(pos.device)))
         ctx.save_for_backward(pos, tri, rast)
         return rast
 
@@ -128,7 +128,24 @@ class _RasterizeFunc(torch.autograd.Function):
         with _device_ctx(pos.device):
             _capi.check(_lib.tsamd_rasterize_backward(pos.data_ptr(), B, V, tri.data_ptr(), int(tri.shape[0]), H, W, rast.data_ptr(),
                                                       g.data_ptr(), grad_pos.data_ptr(), _stream_ptr(pos.device)))
-        return grad_pos, None, None, None, None
+        return grad_pos, None, None, None, None, None
+
+
+# The pair masks of the last rasterised image per device (a by-product of the resolve pass, 2 bits per pixel: which pixels show a
+# different triangle than their right / upper neighbour), for the antialias call that receives the SAME rast tensor unmodified --
+# identity through a weak reference plus the version counter, as for the topology table below.  mesh_rasterizer.py:103-107 is
+# exactly that sequence; any other use (a copy, a slice, an edited image) finds no masks and antialias scans the image itself.
+PAIR_MASKS_FROM_RASTERIZE = os.environ.get("TSSPLAT_AMD_DR_PAIR_MASKS", "1") != "0"
+_last_pair_masks: dict = {}
+
+
+def _pair_masks_for(rast: torch.Tensor):
+    hit = _last_pair_masks.get(rast.device)
+    if hit is not None:
+        masks, ref, version = hit
+        if ref() is rast and version == rast._version:
+            return masks
+    return None
 
 
 def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor, resolution, ranges=None, grad_db: bool = True):
@@ -152,7 +169,12 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
         raise RuntimeError("tssplat_amd.dr.rasterize: resolution out of range (0 .. 8192 pixels per side)")
     if _CHECK_DROPPED and tri.shape[0] > 0:
         _warn_dropped(pos, tri, height, width)
-    rast = _RasterizeFunc.apply(pos, tri, glctx, height, width)
+    masks = None
+    if PAIR_MASKS_FROM_RASTERIZE and height * width > 0:
+        masks = torch.empty((int(_lib.tsamd_pair_masks_bytes(int(pos.shape[0]), height, width)),), dtype=torch.uint8, device=pos.device)
+    rast = _RasterizeFunc.apply(pos, tri, glctx, height, width, masks)
+    if masks is not None:
+        _last_pair_masks[pos.device] = (masks, weakref.ref(rast), rast._version)
     return rast, torch.empty((int(pos.shape[0]), height, width, 0), dtype=torch.float32, device=pos.device)
 
 
@@ -247,7 +269,7 @@ PREPARE_ANTIALIAS = None
 
 class _AntialiasFunc(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, rast, pos, tri, opp, boost):
+    def forward(ctx, color, rast, pos, tri, opp, boost, pair_masks):
         B, H, W, Cn = (int(k) for k in color.shape)
         V, T = int(pos.shape[1]), int(tri.shape[0])
         out = torch.empty_like(color)
@@ -260,8 +282,8 @@ class _AntialiasFunc(torch.autograd.Function):
         with _device_ctx(color.device):
             stream = _stream_ptr(color.device)
             if prepare:
-                _capi.check(_lib.tsamd_antialias_prepare(rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(), B, V, T, H, W,
-                                                         win.data_ptr(), stream))
+                _capi.check(_lib.tsamd_antialias_prepare(rast.data_ptr(), pos.data_ptr(), tri.data_ptr(), opp.data_ptr(),
+                                                         None if pair_masks is None else pair_masks.data_ptr(), B, V, T, H, W, win.data_ptr(), stream))
             _capi.check(_lib.tsamd_antialias(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), win.data_ptr() if prepare else None, tri.data_ptr(),
                                              opp.data_ptr(), B, V, T, H, W, Cn, out.data_ptr(), stream))
         ctx.save_for_backward(color, rast, pos, tri, opp, win)
@@ -277,19 +299,20 @@ class _AntialiasFunc(torch.autograd.Function):
         grad_color = torch.empty_like(color) if ctx.needs_input_grad[0] else None
         grad_pos = torch.empty_like(pos) if ctx.needs_input_grad[2] else None
         if grad_color is None and grad_pos is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         with _device_ctx(color.device):
             _capi.check(_lib.tsamd_antialias_backward(color.data_ptr(), rast.data_ptr(), pos.data_ptr(), win.data_ptr() if win.numel() else None,
                                                       tri.data_ptr(), opp.data_ptr(),
                                                       B, V, T, H, W, Cn, g.data_ptr(), ctx.boost, None if grad_color is None else grad_color.data_ptr(),
                                                       None if grad_pos is None else grad_pos.data_ptr(), _stream_ptr(color.device)))
-        return grad_color, None, grad_pos, None, None, None
+        return grad_color, None, grad_pos, None, None, None, None
 
 
 def antialias(color: torch.Tensor, rast: torch.Tensor, pos: torch.Tensor, tri: torch.Tensor, topology_hash=None, pos_gradient_boost: float = 1.0):
     """``dr.antialias`` (mesh_rasterizer.py:107,128): ``color[B, H, W, C]`` with the silhouette pixels blended by the position
     of the silhouette edge between the pixel centres; differentiable w.r.t. ``color`` and ``pos`` (``rast`` carries none)."""
     color = _check_cuda_f32("color", color)
+    pair_masks = _pair_masks_for(rast)              # (by identity of the tensor dr.rasterize handed out)
     rast = _check_cuda_f32("rast", rast.detach())
     pos = _check_cuda_f32("pos", pos)
     if color.dim() != 4 or rast.dim() != 4 or rast.shape[3] != 4 or tuple(color.shape[:3]) != tuple(rast.shape[:3]):
@@ -302,4 +325,4 @@ def antialias(color: torch.Tensor, rast: torch.Tensor, pos: torch.Tensor, tri: t
     topo = _topology_for(tri) if topology_hash is None else topology_hash
     if not isinstance(topo, TopologyHash) or topo.n_triangles != int(tri.shape[0]) or topo.opp.device != rast.device:
         raise RuntimeError("tssplat_amd.dr.antialias: topology_hash does not belong to this triangle list")
-    return _AntialiasFunc.apply(color, rast, pos, tri, topo.opp, float(pos_gradient_boost))
+    return _AntialiasFunc.apply(color, rast, pos, tri, topo.opp, float(pos_gradient_boost), pair_masks)
