@@ -82,3 +82,18 @@ def sim_sort(name, c):
         it = srt.reshape(nb, N//64, 64).max(2)
         print(f"   {name}: class-sort in blocks of {N}: iterations per 64 items {it.mean():.2f} (ideal {c.mean():.2f}); utilisation {c.sum()/64/it.sum():.3f}")
 sim_sort(which, np.concatenate(ws)*np.concatenate(hs))
+
+
+def sim_coop(name, c, overhead=3.0):
+    """Cooperative walk of big boxes: a wave walks its boxes of <= T candidates lane-per-triangle, then every bigger box with all 64 lanes."""
+    pad = (-len(c)) % 64
+    cc = np.concatenate([c, np.zeros(pad, np.int64)]).reshape(-1, 64)
+    cur = cc.max(1)
+    for T in (16, 32, 64, 128, 256):
+        small = np.where(cc <= T, cc, 0).max(1)
+        big = np.where(cc > T, (cc + 63) // 64 + overhead, 0).sum(1)
+        it = small + big
+        print(f"   {name}: cooperative walk above T={T:3d}: iterations/wave {it.mean():6.1f} (p99 {np.percentile(it, 99):6.1f}, max {it.max():6.1f})   now {cur.mean():.1f} (p99 {np.percentile(cur, 99):.1f}, max {cur.max()})")
+
+
+sim_coop(which, np.concatenate(ws) * np.concatenate(hs))
