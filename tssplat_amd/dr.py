@@ -135,8 +135,12 @@ class _RasterizeFunc(torch.autograd.Function):
 # different triangle than their right / upper neighbour), for the antialias call that receives the SAME rast tensor unmodified --
 # identity through a weak reference plus the version counter, as for the topology table below.  mesh_rasterizer.py:103-107 is
 # exactly that sequence; any other use (a copy, a slice, an edited image) finds no masks and antialias scans the image itself.
+# The by-product costs the resolve pass a second stream of depth keys (+0.06 ms at 120 views x 512^2), so it is produced only
+# while it is being used: a rasterize call that finds the previous masks unclaimed stops producing them, an antialias call that
+# finds none asks for them again.
 PAIR_MASKS_FROM_RASTERIZE = os.environ.get("TSSPLAT_AMD_DR_PAIR_MASKS", "1") != "0"
-_last_pair_masks: dict = {}
+_last_pair_masks: dict = {}     # device -> (masks, weakref(rast), version)
+_pair_masks_wanted: dict = {}   # device -> bool (absent: yes)
 
 
 def _pair_masks_for(rast: torch.Tensor):
@@ -144,7 +148,9 @@ def _pair_masks_for(rast: torch.Tensor):
     if hit is not None:
         masks, ref, version = hit
         if ref() is rast and version == rast._version:
+            del _last_pair_masks[rast.device]          # claimed
             return masks
+    _pair_masks_wanted[rast.device] = True             # an antialias call without masks: the next rasterize makes them
     return None
 
 
@@ -170,7 +176,9 @@ def rasterize(glctx: RasterizeCudaContext, pos: torch.Tensor, tri: torch.Tensor,
     if _CHECK_DROPPED and tri.shape[0] > 0:
         _warn_dropped(pos, tri, height, width)
     masks = None
-    if PAIR_MASKS_FROM_RASTERIZE and height * width > 0:
+    if _last_pair_masks.pop(pos.device, None) is not None:
+        _pair_masks_wanted[pos.device] = False         # the last ones were never claimed by an antialias call
+    if PAIR_MASKS_FROM_RASTERIZE and _pair_masks_wanted.get(pos.device, True) and height * width > 0:
         masks = torch.empty((int(_lib.tsamd_pair_masks_bytes(int(pos.shape[0]), height, width)),), dtype=torch.uint8, device=pos.device)
     rast = _RasterizeFunc.apply(pos, tri, glctx, height, width, masks)
     if masks is not None:
