@@ -43,7 +43,7 @@ int tsamd_rasterize(const float *pos_clip_dev, int64_t batch, int64_t n_vertices
     if (rc) return rc;
     if (n_vertices < 0 || n_triangles < 0 || n_triangles > (int64_t(1) << 24) - 1)
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "negative size or more than 2^24 - 1 triangles (the id + 1 is returned as a float32, exact up to 2^24)");
-    if (batch * ((n_triangles + 255) / 256) > int64_t(INT32_MAX))
+    if ((batch + 7) / 8 * 8 * ((n_triangles + 255) / 256) > int64_t(INT32_MAX))
         return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "batch x triangles / 256 exceeds the grid limit (2^31 - 1 workgroups)");
     const int64_t pixels = batch * int64_t(height) * width;
     if (pixels > 0 && (!workspace_dev || !rast_out_dev)) return capi_fail(TSAMD_ERR_INVALID_ARGUMENT, "workspace_dev / rast_out_dev is null");

@@ -117,10 +117,17 @@ __device__ __forceinline__ void drain(WaveQueue &q, int lane)
             slot[j] = q.image + (have ? q.pixels[k] : 0u);   // (an empty lane reads pixel 0 of its view, which always exists: the load stays unconditional)
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // workgroup scope (served by the L2, not fetched device-coherently): the value is only a FILTER in front of the atomic, and
+        // a stale one is an older = larger key -- it can let a needless atomic through, never hold back a needed one.  1.11 -> 0.99 ms
+        // on the 512-sphere surface.
+        for (int j = 0; j < 3; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
+#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 3   // pricing build: depth reads but no atomics
+            if (key[j] < cur[j] && key[j] == 12345ull) atomicMin(slot[j], key[j]);
+#else
             if (key[j] < cur[j]) atomicMin(slot[j], key[j]);              // (an empty lane's key is all ones: never smaller)
+#endif
     }
     q.count = 0;
 }
@@ -144,8 +151,14 @@ __device__ __forceinline__ void wave_walk(bool mine, int32_t px0, int32_t px1, i
     int32_t px = px0, py = py0;
     Int e0 = r0, e1 = r1, e2 = r2;
     bool active = mine;
+#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 1   // pricing build (tools/ab_raster.py): fetch + set-up only
+    active = false;
+#endif
     while (__ballot(active) != 0ull) {
         bool in = active && (e0 | e1 | e2) >= 0;
+#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 2   // pricing build: the walk without its fragments
+        in = in && px == -7;
+#endif
         unsigned long long key = 0;
         if (in) {
             // oracle/raster_oracle.py::rasterize_ids, operation by operation (this file is compiled without contraction)
@@ -187,12 +200,24 @@ __device__ __forceinline__ void wave_walk(bool mine, int32_t px0, int32_t px1, i
 
 // One lane per (view, triangle); a workgroup is four independent waves (no barrier anywhere).
 __global__ __launch_bounds__(64 * kWavesPerBlock) void rasterize_bin_kernel(const SnapRec *snapped, const int32_t *tri, int64_t n_vertices, int64_t n_tri,
-                                                                             int blocks_per_view, int height, int width, unsigned long long *keys)
+                                                                             int blocks_per_view, int height, int width, unsigned long long *keys, int n_views)
 {
     __shared__ unsigned long long queue_keys[kWavesPerBlock * kQueue];
     __shared__ uint32_t queue_pixels[kWavesPerBlock * kQueue];
-    const int b = int(blockIdx.x) / blocks_per_view;
-    const int64_t t_own = int64_t(int(blockIdx.x) - b * blocks_per_view) * (64 * kWavesPerBlock) + threadIdx.x;
+    // n_views > 0: XCD-affine order -- workgroup i lands on XCD i % 8 (observed; speed only), so view v is given to the workgroups
+    // with i % 8 == v % 8 and its depth image lives in ONE L2 instead of migrating between eight on every atomic.  Pays when many
+    // fragments fight for a pixel (512-sphere surface, 41 per pixel: 0.99 -> 0.91 ms); costs a little balance otherwise (the launcher decides).
+    int b, jb;
+    if (n_views > 0) {
+        const int xcd = int(blockIdx.x) & 7, jq = int(blockIdx.x) >> 3;
+        b = (jq / blocks_per_view) * 8 + xcd;
+        jb = jq % blocks_per_view;
+        if (b >= n_views) return;
+    } else {
+        b = int(blockIdx.x) / blocks_per_view;
+        jb = int(blockIdx.x) - b * blocks_per_view;
+    }
+    const int64_t t_own = int64_t(jb) * (64 * kWavesPerBlock) + threadIdx.x;
     const int lane = int(threadIdx.x) & 63, wave = int(threadIdx.x) >> 6;
     WaveQueue q;
     q.keys = queue_keys + wave * kQueue;
@@ -640,8 +665,12 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
                            batch * n_vertices, n_vertices, double(width), double(height), snapped, view_flags);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         const int64_t blocks_per_view = (n_tri + 255) / 256;   // (256 = 64 * kWavesPerBlock triangles per workgroup)
-        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(unsigned(batch * blocks_per_view)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri,
-                           int(blocks_per_view), height, width, keys);
+        // XCD-affine views (rasterize_bin_kernel) when the depth atomics are dense -- more triangles than pixels -- and the views
+        // divide evenly among the eight XCDs
+        const bool xcd_views = n_tri >= int64_t(height) * width && (batch % 8 == 0 || batch >= 64);
+        const int64_t bin_blocks = (xcd_views ? (batch + 7) / 8 * 8 : batch) * blocks_per_view;
+        hipLaunchKernelGGL(rasterize_bin_kernel, dim3(unsigned(bin_blocks)), dim3(256), 0, stream, snapped, tri, n_vertices, n_tri,
+                           int(blocks_per_view), height, width, keys, xcd_views ? int(batch) : 0);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         // triangles that straddle the eye plane (none in a view without a vertex at w <= 0)
         hipLaunchKernelGGL(rasterize_clip_kernel, dim3(unsigned(std::min<int64_t>(kClipBlocks, blocks_per_view))), dim3(256), 0, stream,
