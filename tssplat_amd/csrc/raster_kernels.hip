@@ -1,6 +1,6 @@
 // gfx950 kernels of the renderer slice: rasterize + interpolate, the two nvdiffrast operators
-// /root/reference/renderers/mesh_rasterizer.py:103,117,145,153 calls.  First slice: forward rasterisation (triangle
-// id, perspective-correct barycentrics, z/w), interpolate forward and backward.  No antialias, no rasterize backward.
+// /root/reference/renderers/mesh_rasterizer.py:103,117,145,153 calls: forward rasterisation (triangle id, perspective-correct
+// barycentrics, z/w) and its backward, interpolate forward and backward.  (antialias: aa_kernels.hip.)
 //
 // The specification these kernels implement is oracle/raster_oracle.py (a restatement of nvdiffrast's published
 // algorithm with every open choice fixed there); coverage and the depth test repeat its float64 / integer operations
@@ -11,11 +11,14 @@
 //                          box in one wave-uniform loop, depth from a float32 plane, covered fragments into a per-wave
 //                          LDS queue that is drained in batches: read of the depth image, then (rarely) a 64-bit
 //                          atomicMin of (depth32 << 32 | triangle)
-//   rasterize_resolve_kernel  one lane per pixel: winning triangle -> (u, v, z/w, id + 1)
+//   rasterize_clip_kernel  the rare path: triangles with a vertex at w <= 0, clipped against the near plane, same integer rules
+//   rasterize_resolve_kernel  one lane per pixel: winning triangle -> (u, v, z/w, id + 1); optional by-product: the pair masks
+//                          (which pixels differ from their right / upper neighbour) that the antialias kernels start from
 //   interpolate_kernel / interpolate_backward_kernel  one lane per pixel
 //
-// Bound: HBM / L2 atomics (12 B of indices + 3 x 16 B of clip-space vertices per triangle and view, 8 B of key and 16 B of
-// output per pixel); no MFMA anywhere.
+// Bound: the depth image -- L2 atomics and the reads in front of them (pricing builds, profiles/r04_raster_experiments.md: walk
+// 0.46 ms, fragment queue + depth reads 0.23, atomics 0.31 of 1.10 ms on the 512-sphere surface); 12 B of indices + 3 x 16 B of
+// snapped vertices per triangle and view, 8 B of key and 16 B of output per pixel; no MFMA anywhere.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
