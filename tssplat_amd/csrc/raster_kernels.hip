@@ -404,70 +404,101 @@ __global__ __launch_bounds__(256) void rasterize_clip_kernel(const float4 *pos, 
 // A wave holds 64 consecutive pixels of the flattened [view, row, column] image -- what the pair masks are indexed by, and the
 // order in which keys are read and `rast` is written as one stream.  (Four rows x 64 columns per workgroup, the upper neighbour
 // handed over in LDS, was tried: the strided streams alone cost 138 -> 172 us on 120 views x 512^2.)
+#ifndef TSAMD_RESOLVE_PPL
+#define TSAMD_RESOLVE_PPL 4
+#endif
+constexpr int kResolvePixels = TSAMD_RESOLVE_PPL;   // 64-pixel chunks per wave, all their key loads in flight together
+
 __global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t batch,
                                                                 int height, int width, const unsigned long long *keys, float4 *rast,
                                                                 unsigned long long *pair_masks)
 {
-    const int64_t hw = int64_t(height) * width;
+    constexpr int K = kResolvePixels;
+    const int64_t hw = int64_t(height) * width, total = batch * hw;
     const int lane = int(threadIdx.x) & 63;
-    const int64_t gid = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    const bool have = gid < batch * hw;
+    // pixel k of this lane: chunk (first chunk of the wave + k), lane-th pixel -- every load of a wave is one contiguous 512 bytes
+    const int64_t gid0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6))) * (64 * K);
+    int64_t gid[K], b[K];
+    int px[K], py[K];
+    bool have[K];
     // view / row / column without a per-lane 64-bit division: the view of the wave's first pixel on the scalar unit (a wave crosses
-    // at most one view boundary unless the image has fewer than 64 pixels)
-    int64_t b;
-    uint32_t pix;
-    if (hw >= 64) {
-        const int64_t gid0 = int64_t(blockIdx.x) * blockDim.x + __builtin_amdgcn_readfirstlane(int(threadIdx.x & ~63u));
-        const int64_t b0 = gid0 / hw;
-        const int64_t off = gid - b0 * hw;
-        b = off >= hw ? b0 + 1 : b0;
-        pix = uint32_t(off >= hw ? off - hw : off);
-    } else {
-        b = gid / hw;
-        pix = uint32_t(gid - b * hw);
+    // at most one view boundary unless the image has fewer than 64 K pixels)
+    const int64_t b0 = hw >= 64 * K ? gid0 / hw : 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        gid[k] = gid0 + 64 * k + lane;
+        have[k] = gid[k] < total;
+        uint32_t pix;
+        if (hw >= 64 * K) {
+            const int64_t off = gid[k] - b0 * hw;
+            b[k] = off >= hw ? b0 + 1 : b0;
+            pix = uint32_t(off >= hw ? off - hw : off);
+        } else {
+            b[k] = gid[k] / hw;
+            pix = uint32_t(gid[k] - b[k] * hw);
+        }
+        py[k] = int(pix / uint32_t(width));   // (pix < 2^26: height, width <= 8192)
+        px[k] = int(pix - uint32_t(py[k]) * uint32_t(width));
     }
-    const int py = int(pix / uint32_t(width)), px = int(pix - uint32_t(py) * uint32_t(width));   // (pix < 2^26: height, width <= 8192)
     // all global loads first, together: the kernel is bound by the latency of its key loads (a second round trip behind the first
     // costs as much again)
-    const bool want_right = pair_masks && have && px + 1 < width && lane == 63;   // (the other lanes ask their neighbour lane)
-    const bool want_up = pair_masks && have && py + 1 < height;
-    const unsigned long long key = have ? keys[gid] : kNoFragment;
-    const unsigned long long key_right = want_right ? keys[gid + 1] : 0ull, key_up = want_up ? keys[gid + width] : 0ull;
+    unsigned long long key[K], key_up[K], key_right = 0ull;
+    bool want_up[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        want_up[k] = pair_masks && have[k] && py[k] + 1 < height;
+        key[k] = have[k] ? keys[gid[k]] : kNoFragment;
+        key_up[k] = want_up[k] ? keys[gid[k] + width] : 0ull;
+    }
+    // (the right neighbour of a chunk's last pixel is the next chunk's first: a lane of this wave, except behind the last chunk)
+    const bool want_right = pair_masks && have[K - 1] && px[K - 1] + 1 < width && lane == 63;
+    if (want_right) key_right = keys[gid[K - 1] + 1];
     if (pair_masks) {
         // by-product for tsamd_antialias_prepare: does the pixel's triangle differ from its right / upper neighbour's?  Two 64-bit
-        // words per 64 pixels (this wave), what antialias_detect_kernel would otherwise find by reading the whole `rast` image back.
-        const uint32_t id = uint32_t(key);
-        const uint32_t next = uint32_t(__shfl_down(int(id), 1));   // (every lane takes part: lane 62 reads lane 63)
-        const uint32_t right = lane == 63 ? (want_right ? uint32_t(key_right) : id) : next;
-        const uint32_t up = want_up ? uint32_t(key_up) : id;
-        const bool c0 = have && px + 1 < width && right != id;
-        const bool c1 = have && py + 1 < height && up != id;
-        const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
-        if (lane == 0 && have) {
-            pair_masks[2 * (gid >> 6)] = m0;
-            pair_masks[2 * (gid >> 6) + 1] = m1;
+        // words per 64 pixels, what antialias_detect_kernel would otherwise find by reading the whole `rast` image back.
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t id = uint32_t(key[k]);
+            const uint32_t next = uint32_t(__shfl_down(int(id), 1));   // (every lane takes part: lane 62 reads lane 63)
+            uint32_t beyond = id;                                       // lane 63's right neighbour
+            if (k + 1 < K)
+                beyond = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(key[k + 1 < K ? k + 1 : k]))));
+            else if (want_right)
+                beyond = uint32_t(key_right);
+            const uint32_t right = lane == 63 ? beyond : next;
+            const uint32_t up = want_up[k] ? uint32_t(key_up[k]) : id;
+            const bool c0 = have[k] && px[k] + 1 < width && right != id;
+            const bool c1 = have[k] && py[k] + 1 < height && up != id;
+            const unsigned long long m0 = __ballot(c0), m1 = __ballot(c1);
+            if (lane == 0 && have[k]) {
+                pair_masks[2 * (gid[k] >> 6)] = m0;
+                pair_masks[2 * (gid[k] >> 6) + 1] = m1;
+            }
         }
     }
-    if (!have) return;
-    if (key == kNoFragment) {
-        rast[gid] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (!have[k]) continue;
+        if (key[k] == kNoFragment) {
+            rast[gid[k]] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const int64_t t = int64_t(key[k] & 0xFFFFFFFFull);
+        const float4 *pv = pos + b[k] * n_vertices;
+        const float4 v0 = pv[tri[3 * t]], v1 = pv[tri[3 * t + 1]], v2 = pv[tri[3 * t + 2]];
+        const float fx = (float(px[k]) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py[k]) + 0.5f) / float(height) * 2.f - 1.f;
+        const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
+        const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
+        const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
+        const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+        float s = a0 + a1 + a2;
+        s = s == 0.f ? 1.f : s;
+        const float b0f = a0 / s, b1f = a1 / s, b2f = 1.f - b0f - b1f;
+        const float z = b0f * v0.z + b1f * v1.z + b2f * v2.z;
+        float w = b0f * v0.w + b1f * v1.w + b2f * v2.w;
+        w = w == 0.f ? 1.f : w;
+        rast[gid[k]] = make_float4(fminf(fmaxf(b0f, 0.f), 1.f), fminf(fmaxf(b1f, 0.f), 1.f), fminf(fmaxf(z / w, -1.f), 1.f), float(t + 1));
     }
-    const int64_t t = int64_t(key & 0xFFFFFFFFull);
-    const float4 *pv = pos + b * n_vertices;
-    const float4 v0 = pv[tri[3 * t]], v1 = pv[tri[3 * t + 1]], v2 = pv[tri[3 * t + 2]];
-    const float fx = (float(px) + 0.5f) / float(width) * 2.f - 1.f, fy = (float(py) + 0.5f) / float(height) * 2.f - 1.f;
-    const float p0x = v0.x - fx * v0.w, p0y = v0.y - fy * v0.w;
-    const float p1x = v1.x - fx * v1.w, p1y = v1.y - fy * v1.w;
-    const float p2x = v2.x - fx * v2.w, p2y = v2.y - fy * v2.w;
-    const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-    float s = a0 + a1 + a2;
-    s = s == 0.f ? 1.f : s;
-    const float b0 = a0 / s, b1 = a1 / s, b2 = 1.f - b0 - b1;
-    const float z = b0 * v0.z + b1 * v1.z + b2 * v2.z;
-    float w = b0 * v0.w + b1 * v1.w + b2 * v2.w;
-    w = w == 0.f ? 1.f : w;
-    rast[gid] = make_float4(fminf(fmaxf(b0, 0.f), 1.f), fminf(fmaxf(b1, 0.f), 1.f), fminf(fmaxf(z / w, -1.f), 1.f), float(t + 1));
 }
 
 // ---- scatter with runs ----
@@ -680,7 +711,7 @@ hipError_t launch_rasterize(const float *pos_clip, int64_t batch, int64_t n_vert
                            reinterpret_cast<const float4 *>(pos_clip), snapped, tri, view_flags, batch, n_vertices, n_tri, height, width, keys);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for(pixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
+    hipLaunchKernelGGL(rasterize_resolve_kernel, dim3(blocks_for((pixels + kResolvePixels - 1) / kResolvePixels)), dim3(256), 0, stream, reinterpret_cast<const float4 *>(pos_clip), tri,
                        n_vertices, batch, height, width, keys, reinterpret_cast<float4 *>(rast), static_cast<unsigned long long *>(pair_masks));
     return hipGetLastError();
 }
