@@ -577,6 +577,24 @@ def test_interpolate_bounds_on_foreign_rast():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,spheres,views,res", [("kuhn8", 4, 8, (32, 32)), ("kuhn8", 4, 16, (24, 40)), ("kuhn4", 6, 66, (16, 16)), ("kuhn8", 4, 5, (32, 32))])
+def test_rasterize_with_more_triangles_than_pixels(kind, spheres, views, res):
+    """The launch order changes when the depth atomics are dense (more triangles than pixels and a batch that divides among the
+    XCDs: every view's workgroups on one XCD): same bit-exact ids, also for batches that are not a multiple of eight and for
+    the fallback order (5 views)."""
+    import torch
+    import tssplat_amd.dr as dr
+    pos_clip, tri, _ = _surface_scene(kind, spheres, views)
+    assert tri.shape[0] >= res[0] * res[1]
+    ref = R.rasterize(pos_clip, tri, res)
+    rast, _ = dr.rasterize(dr.RasterizeCudaContext(), torch.from_numpy(pos_clip).cuda(), torch.from_numpy(tri).cuda(), resolution=list(res), grad_db=False)
+    out = rast.cpu().numpy()
+    assert (ref[..., 3] > 0).mean() > 0.05
+    assert np.array_equal(out[..., 3], ref[..., 3])
+    assert np.abs(out[..., :3] - ref[..., :3])[ref[..., 3] > 0].max() <= 2e-4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("res", [(64, 64), (50, 128), (33, 20), (7, 192), (128, 96)])
 def test_pair_masks_of_the_resolve_pass_equal_a_scan_of_rast(res):
     """tsamd_rasterize's optional by-product (which pixels differ from their right / upper neighbour, 2 bits per pixel) against
