@@ -673,6 +673,28 @@ def test_near_plane_clipping_on_gpu():
     assert (pos0[tri[ids], 3] <= 0).any()
 
 
+@pytest.mark.gpu
+def test_near_plane_clipping_in_a_large_batch():
+    """The clip kernel scans the per-view flags 64 views at a time: one view that needs clipping among 70 that do not."""
+    import torch
+    import tssplat_amd.dr as dr
+    H, W = 24, 32
+    clip = _ground_scene()
+    v = np.array([[-30.0, 0, 8], [30.0, 0, 8], [0.0, 0, -40], [-30, 0, -40], [30, 0, -40]])
+    tri = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 2]], np.int32)
+    front = clip(v * [1, 1, 0.2] - [0, 0, 12])                      # everything in front of the camera
+    assert (front[:, 3] > 0).all()
+    pos = np.stack([front] * 70)
+    pos[66] = clip(v)
+    ref = R.rasterize(pos[[0, 66]], tri, (H, W))
+    out, _ = dr.rasterize(dr.RasterizeCudaContext(), torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), resolution=[H, W], grad_db=False)
+    out = out.cpu().numpy()
+    assert (ref[1, ..., 3] > 0).sum() > 100 and not np.array_equal(ref[0, ..., 3], ref[1, ..., 3])
+    assert np.array_equal(out[66, ..., 3], ref[1, ..., 3])
+    for b in (0, 1, 63, 64, 65, 67, 69):
+        assert np.array_equal(out[b, ..., 3], ref[0, ..., 3])
+
+
 def test_dropped_triangle_counter():
     """dr.count_dropped_triangles (TSSPLAT_AMD_DR_CHECK=1 makes dr.rasterize warn with it): the (view, triangle) pairs this slice
     drops whole -- a vertex that is not finite or beyond the +-16384-pixel guard band (a finite vertex at w <= 0 is clipped)."""
