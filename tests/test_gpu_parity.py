@@ -423,7 +423,9 @@ def test_replicated_sphere_beyond_4_gib(ext):
     sc = scenes.make_scene("kuhn19", 1)
     n1, m1 = sc.n_vertices, sc.n_tets
     x1 = scenes.deform(sc, 0.3)                       # many inverted tets: both energy terms live
-    ts1 = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    # (explicit max_threads = the default value: a lone sphere would otherwise get the small-batch tiling -- smaller tiles, another
+    # summation order -- while the 1 700 copies get the large-batch one)
+    ts1 = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), max_threads=768)
     c1, c2 = 2e-4, 2e-4
     e1, g1 = _eval_gpu(ext, ts1, x1, c1, c2, 4)
     rest = np.tile(sc.rest, (S, 1))
