@@ -251,3 +251,23 @@ def test_cpp_autograd_extension_builds_and_binds():
     x = torch.zeros(4, 3)
     with pytest.raises(RuntimeError, match="float32 GPU tensor"):
         ext.energy_eval(x, 0, 1.0, 1.0, 2)                    # CPU tensor: rejected before the library is called
+
+
+def test_small_batches_get_smaller_tiles():
+    """Default options, at most 1 024 tiles: the plan is re-tiled at 768 owned tets per tile (a small batch pays for a tile's latency,
+    not for its halo): 3 k-tet spheres in four tiles instead of three.  Any explicit tiling option, or a large batch, keeps the
+    fullest tiles that fit; both tilings replay to the oracle."""
+    from tssplat_amd import tet_spheres_ext as ext
+    sc = scenes.make_scene("kuhn8", 4)
+    small = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True)
+    full = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, max_threads=768)
+    assert small.plan_info()["n_tiles"] == 16 and full.plan_info()["n_tiles"] == 12
+    assert small.plan_info()["max_slots"] < full.plan_info()["max_slots"]
+    cache = O.prepare(sc.rest, sc.tets)
+    x = scenes.deform(sc, 0.2, seed=3)
+    E, Es, Eb, g = O.energy_and_grad(x, cache, 3e-5, 2e-4, 2)
+    for ts in (small, full):
+        E2, _, _, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 2)
+        assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()
+    big = scenes.make_scene("kuhn8", 400)                      # 1 200 tiles by default: left alone
+    assert ext.TetSpheres(big.rest.reshape(-1), big.tets.reshape(-1), host_only=True).plan_info()["n_tiles"] == 1200
