@@ -62,7 +62,9 @@ typedef struct tsamd_options {
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
     int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU) */
     int32_t max_threads;       /* workgroup size cap, multiple of 64, <= 768; 0 = 768 */
-    int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto            */
+    int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto: the fullest tiles that fit, except that a
+                                * plan of <= 1024 tiles built with lds_budget_bytes = max_threads = target_owned = 0 is re-tiled at
+                                * 768 (a small batch pays for a tile's latency, not for its halo) */
     int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
