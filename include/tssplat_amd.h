@@ -61,15 +61,19 @@ typedef struct tsamd_options {
     int32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
     int32_t lds_budget_bytes;  /* LDS per workgroup a tile may use; 0 = 81920 (two workgroups per gfx950 CU) */
-    int32_t max_threads;       /* workgroup size cap, multiple of 64, <= 768; 0 = 768 */
+    int32_t max_threads;       /* workgroup size cap, multiple of 64, <= 768 (see slots_per_thread for the other lane layouts); 0 = 768 */
     int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto: the fullest tiles that fit, except that a
                                 * plan of <= 1024 tiles built with lds_budget_bytes = max_threads = target_owned = 0 is re-tiled at
                                 * 768 (a small batch pays for a tile's latency, not for its halo) */
-    int32_t balance_slots;     /* 1 = interleave owned/halo slots across lanes (default), 0 = owned first */
+    int32_t reserved0;         /* (0.1: balance_slots.  Owned and halo slots are always interleaved across the lanes now) */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
-    int32_t debug_shuffle;     /* experiments: bit0 = spread a tile's tets over lanes, bit1 = no LDS-conflict-aware ordering */
-    int32_t slots_per_thread;  /* tets streamed per lane: 0 or 2 (the only layout the kernels are built for; 4 is rejected) */
+    int32_t debug_flags;       /* bit1 = no LDS-conflict-aware neighbour ordering (measurements); other bits ignored */
+    int32_t slots_per_thread;  /* tets per lane: 0 = 2.  Lane layouts with a kernel: 2 (max_threads <= 768, two 80 KiB workgroups per
+                                * CU: the default, every operator variant); 3 (max_threads <= 512, or <= 1024 for one workgroup per
+                                * CU) and 4 (max_threads <= 768): fewer, fatter waves, built-in operator only -- with lds_budget_bytes
+                                * up to 163840 these hold a whole ~3 k-tet sphere as ONE tile (no halo, no shared vertices).
+                                * Anything else is TSAMD_ERR_INVALID_ARGUMENT. */
     int32_t rebuild_dminv;     /* 1 = keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
                                 * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per
                                 * evaluation, entries of Dm^-1 within 2.8e-7 relative of the exact inverse instead of
@@ -96,18 +100,26 @@ typedef struct tsamd_plan_info {
 typedef struct tsamd_tile_view {
     int32_t n_slots, n_owned, s_pad, n_verts, n_excl;
     int64_t stage_off;
-    int32_t n_inc4;           /* incidence list length in 4-entry chunks                           */
-    const uint32_t *planes;   /* n_planes planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]
-                               * (+ L[e,e], L[e,n_0..3], L[n_0..3,e] as fp32 with an explicit operator)    */
-    const uint16_t *inc;      /* 4*n_inc4 entries (slot << 2 | a), grouped by local vertex          */
-    const uint16_t *inc_off;  /* n_verts + 1 chunk offsets                                          */
-    const int32_t *gvid;      /* n_verts global vertex ids, exclusive ones first                    */
-    const int32_t *slot_tet;  /* s_pad global tet ids (-1 = padding)                                */
-    const float *rest;        /* rebuild_dminv plans: n_verts x float4 rest positions (tile vertex order), else NULL */
+    int32_t n_rows;            /* rows of the tile's per-vertex force array = most slots any tile vertex meets (<= 64) */
+    int32_t rec_base;          /* LDS byte address of record 0: the neighbour tokens are (rec_base + 48 idx) / 4 + rot    */
+    const uint32_t *planes;    /* n_planes planes of s_pad dwords: lv01, lv23, nb01, nb23, dminv[0..8]
+                                * (+ L[e,e], L[e,n_0..3], L[n_0..3,e] as fp32 with an explicit operator);
+                                * a 16-bit vertex field = local vertex | rank << 10                                      */
+    const uint16_t *row_start; /* 72 entries: row r of the force array starts at entry row_start[r]; entry (v, r) of
+                                * local vertex v = row_start[r] + v (vertices are numbered by falling slot count)        */
+    const int32_t *gvid;       /* n_verts global vertex ids (a vertex met by more than 64 slots appears several times)   */
+    const int32_t *vdst;       /* n_verts destinations: >= 0 row of grad (the vertex is this tile's alone), < 0: staging
+                                * row ~vdst, summed by the finish kernel                                                  */
+    const int32_t *slot_tet;   /* s_pad global tet ids (-1 = padding)                                                     */
+    const float *rest;         /* rebuild_dminv plans: n_verts x float4 rest positions (tile vertex order), else NULL    */
 } tsamd_tile_view;
 
 const char *tsamd_last_error(void);
 const char *tsamd_version(void);
+/* Bumped whenever a struct layout or a signature of this header changes incompatibly (0.1 had no such call: a caller that
+ * cannot find the symbol is talking to an older library).  Compare with TSAMD_ABI_VERSION of the header you compiled against. */
+#define TSAMD_ABI_VERSION 2
+int32_t tsamd_abi_version(void);
 
 /*
  * rest_xyz: n_vertices*3 float32 (host), tets: n_tets*4 int32 (host, 0-based).
@@ -141,7 +153,8 @@ int64_t tsamd_num_tets(const tsamd_handle *h);
 int tsamd_get_plan_info(const tsamd_handle *h, tsamd_plan_info *out);
 int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out);
 /* finish lists: vertex k (global id vid[k]) = sum of staging rows [off[k], off[k+1]);
- * idx[tile.stage_off + j] = the staging row the tile's j-th shared vertex writes (off[n_finish] entries) */
+ * idx[tile.stage_off + j] = the staging row the tile's j-th shared tile vertex (in tile vertex order) writes -- the same
+ * rows tsamd_tile_view.vdst names (off[n_finish] entries) */
 int tsamd_get_finish_lists(const tsamd_handle *h, int64_t *n_finish, const int32_t **vid,
                            const int32_t **off, const int32_t **idx);
 /* face adjacency computed at create time: 4 ints per tet, -1 = boundary face */

@@ -77,7 +77,6 @@ int main(void)
     memset(&opt, 0, sizeof opt);
     opt.struct_size = (int32_t)sizeof opt;
     opt.device = 0;
-    opt.balance_slots = 1;
     opt.lds_budget_bytes = 24000; /* several tiles: halo slots, staged vertices and the finish kernel take part */
     if (tsamd_create(rest, NV, tets, NT, &opt, &h) != TSAMD_OK) {
         fprintf(stderr, "create: %s\n", tsamd_last_error());

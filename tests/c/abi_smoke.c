@@ -23,7 +23,6 @@ int main(void)
     memset(&opt, 0, sizeof opt);
     opt.struct_size = (int32_t)sizeof opt;
     opt.device = -1;
-    opt.balance_slots = 1;
     opt.host_only = 1; /* plan only: no HIP call is made */
     if (tsamd_create(rest, 5, tets, 2, &opt, &h) != TSAMD_OK) {
         fprintf(stderr, "create: %s\n", tsamd_last_error());

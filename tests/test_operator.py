@@ -50,7 +50,7 @@ def _replay(ext, sc, L, kw, cases=((0.02, 2, 1.0), (0.3, 4, 0.5)), symmetric=Fal
     ("kuhn8", 2, {}),
     ("kuhn12", 1, {}),                                              # bisected: halo slots carry column weights
     ("kuhn12", 1, dict(max_threads=640, lds_budget_bytes=100000)),
-    ("kuhn12", 1, dict(debug_shuffle=2)),                           # no conflict-aware re-ordering of the neighbours
+    ("kuhn12", 1, dict(debug_flags=2)),                           # no conflict-aware re-ordering of the neighbours
     ("delaunay700", 2, dict(lds_budget_bytes=40000)),
 ])
 def test_explicit_operator_replays_to_oracle(ext, kind, S, kw):
@@ -73,7 +73,7 @@ def test_explicit_uniform_operator_equals_default(ext):
     assert ts_d.plan_info()["n_planes"] == 13 and ts_x.plan_info()["n_planes"] == 18    # (the umbrella is symmetric)
     assert ts_x.plan_info()["block_threads"] == ts_d.plan_info()["block_threads"] and ts_x.plan_info()["lds_bytes"] == ts_d.plan_info()["lds_bytes"]
     for a, b in zip(TE.plan_tiles(ts_d), TE.plan_tiles(ts_x)):
-        assert np.array_equal(a["planes"], b["planes"][:13]) and np.array_equal(a["inc"], b["inc"])
+        assert np.array_equal(a["planes"], b["planes"][:13]) and np.array_equal(a["row_start"], b["row_start"]) and np.array_equal(a["vdst"], b["vdst"])
     x = scenes.deform(sc, 0.1)
     r_d = TE.emulate(ts_d, x, 5e-5, 2e-4, 2)
     r_x = TE.emulate(ts_x, x, 5e-5, 2e-4, 2)
@@ -141,5 +141,7 @@ def test_operator_csr_is_validated(ext):
     # the tile kernels are compiled for at most 768 threads and two slots per lane
     with pytest.raises(RuntimeError, match="max_threads exceeds"):
         ext.TetSpheres(v, t, host_only=True, max_threads=1024)
-    with pytest.raises(RuntimeError, match="slots_per_thread must be 0 or 2"):
-        ext.TetSpheres(v, t, host_only=True, slots_per_thread=4)
+    with pytest.raises(RuntimeError, match="slots_per_thread must be 0, 2, 3 or 4"):
+        ext.TetSpheres(v, t, host_only=True, slots_per_thread=5)
+    with pytest.raises(RuntimeError, match="built-in operator"):
+        ext.TetSpheres(v, t, host_only=True, slots_per_thread=4, operator=csr)

@@ -2,11 +2,13 @@
 
 Walks the host copy of a tiling plan (through the C ABI's introspection calls)
 and performs, tile by tile, exactly the passes of
-tssplat_amd/csrc/kernels.hip::tile_energy_kernel in numpy float64, followed by
-the finish kernel's staging sum.  If this matches the oracle, the plan data
-(local indices, halo, owned flags, Dm^-1 planes, exclusive/shared vertex
-split, finish lists) is right, and a GPU mismatch can only come from the
-kernel code itself.
+tssplat_amd/csrc/kernels.hip::tile_energy_kernel in numpy float64 -- the
+scatter of every slot's four corner forces into the tile's per-vertex force
+array (row table + vertex + rank) and the row-by-row sums included -- followed
+by the finish kernel's staging sum.  If this matches the oracle, the plan data
+(local vertices and ranks, halo, owned order, record tokens, Dm^-1 planes, row
+table, destinations, finish lists) is right, and a GPU mismatch can only come
+from the kernel code itself.
 """
 from __future__ import annotations
 
@@ -16,7 +18,8 @@ import numpy as np
 
 from tssplat_amd import _capi
 
-OWNED = 0x8000
+ROW_TABLE_ENTRIES = 72
+MAX_RANK = 64
 
 
 def plan_tiles(ts):
@@ -27,13 +30,14 @@ def plan_tiles(ts):
         _capi.check(lib.tsamd_get_tile(ts._handle(), t, C.byref(tv)))
         sp = tv.s_pad
         planes = np.ctypeslib.as_array(tv.planes, shape=(info["n_planes"], sp)).copy()
-        inc = np.ctypeslib.as_array(tv.inc, shape=(max(4 * tv.n_inc4, 1),)).copy()[:4 * tv.n_inc4]
-        inc_off = np.ctypeslib.as_array(tv.inc_off, shape=(tv.n_verts + 1,)).copy()
+        row_start = np.ctypeslib.as_array(tv.row_start, shape=(ROW_TABLE_ENTRIES,)).copy()
         gvid = np.ctypeslib.as_array(tv.gvid, shape=(tv.n_verts,)).copy()
+        vdst = np.ctypeslib.as_array(tv.vdst, shape=(tv.n_verts,)).copy()
         slot_tet = np.ctypeslib.as_array(tv.slot_tet, shape=(sp,)).copy()
         rest = np.ctypeslib.as_array(tv.rest, shape=(tv.n_verts, 4)).copy() if bool(tv.rest) else None
         yield dict(n_slots=tv.n_slots, n_owned=tv.n_owned, s_pad=sp, n_verts=tv.n_verts, n_excl=tv.n_excl,
-                   stage_off=tv.stage_off, planes=planes, gvid=gvid, slot_tet=slot_tet, inc=inc, inc_off=inc_off, rest=rest)
+                   stage_off=tv.stage_off, n_rows=tv.n_rows, rec_base=tv.rec_base, planes=planes, gvid=gvid, vdst=vdst,
+                   slot_tet=slot_tet, row_start=row_start, rest=rest)
 
 
 def finish_lists(ts):
@@ -94,18 +98,24 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
     vid, off, sdst = finish_lists(ts)
     for T in plan_tiles(ts):
         sp, pl = T["s_pad"], T["planes"]
-        ZS = sp
-        lv16 = np.stack([pl[0] & 0x7fff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
-        assert np.all(lv16 % 16 == 0), "vertex fields are byte offsets into float4 positions"
-        lv = lv16 // 16
-        owned = (pl[0] & OWNED) != 0
-        assert np.array_equal(owned, (pl[2] & OWNED) != 0), "owned bit must agree in lv and nbr planes"
-        # neighbour fields are record tokens 12 * idx + rot (plan.h: record_token); a face without a usable
+        spt = info["slots_per_thread"]
+        nq = sp // spt
+        slots = np.arange(sp)
+        perm = (slots % spt) * nq + slots // spt            # LDS record index of every slot = its item number in the tile
+        f16 = np.stack([pl[0] & 0xffff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
+        lv, rank = f16 & 0x3ff, f16 >> 10
+        real = T["slot_tet"] >= 0
+        assert real.sum() == T["n_slots"] and np.all(f16[~real] == 0)
+        assert lv[real].max() < T["n_verts"] <= 1023
+        owned = perm < T["n_owned"]                        # (no owned bit: the items below n_owned are the owned ones)
+        assert np.all(real[owned]) and np.all(perm[real] < T["n_slots"])
+        # neighbour fields are record tokens rec_base / 4 + 12 * idx + rot (plan.h: record_token); a face without a usable
         # neighbour points at the slot's own record
-        tok = np.stack([pl[2] & 0x7fff, (pl[2] >> 16) & 0x7fff, pl[3] & 0x7fff, (pl[3] >> 16) & 0x7fff], axis=1).astype(np.int64)
+        RB = T["rec_base"]
+        assert RB % 16 == 0 and RB == 320 + (32 if T["rest"] is not None else 16) * ((T["n_verts"] + 3) & ~3) + 256
+        tok = np.stack([pl[2] & 0xffff, pl[2] >> 16, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64) - RB // 4
         nb = tok // 12
-        assert np.array_equal(tok % 12, (nb >> 3) & 3), "token = 12 * idx + ((idx >> 3) & 3)"
-        assert np.all((pl[2] >> 31) == 0) and np.all(((pl[3] >> 15) & 1) == 0) and np.all((pl[3] >> 31) == 0)
+        assert np.all(tok >= 0) and np.array_equal(tok % 12, (nb >> 3) & 3), "token = rec_base / 4 + 12 * idx + ((idx >> 3) & 3)"
         if T["rest"] is None:
             dminv = pl[4:13].view(np.float32).astype(np.float64).T.reshape(sp, 3, 3)
         else:                                    # rebuild_dminv plan: Dm^-1 from the tile's rest positions (exact here)
@@ -116,6 +126,7 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
             dminv = np.zeros((sp, 3, 3))
             dminv[real] = np.linalg.inv(Dm[real])
         assert owned.sum() == T["n_owned"]
+        ZS = sp
         xs = x[T["gvid"]]
         p = xs[lv]                                            # [sp,4,3]
         Ds = np.stack([p[:, 1] - p[:, 0], p[:, 2] - p[:, 0], p[:, 3] - p[:, 0]], axis=2)
@@ -130,12 +141,6 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
             pen, dpen = 0 * Jm, 0 * Jm
         Eb += float(pen[owned].sum())
         scal = np.where(owned, c2 * dpen, 0.0)
-        # LDS planes are addressed by lds_index(slot) = (slot & 3) * nq + (slot >> 2); neighbour and
-        # incidence entries hold those indices, the zero slot sits at index s_pad
-        spt = info["slots_per_thread"]
-        nq = sp // spt
-        slots = np.arange(sp)
-        perm = (slots % spt) * nq + slots // spt
         Fz = np.zeros((sp + 1, 9))
         Fz[perm] = F.reshape(sp, 9)
         self_idx = perm                        # LDS record of every slot
@@ -158,30 +163,32 @@ def emulate(ts, x, c1, c2, order, grad_output=1.0):
         Q = wd[:, None] * H + (wc[:, :, None] * Hz[nb]).sum(axis=1)
         P = c1 * Q.reshape(sp, 3, 3) + scal[:, None, None] * _cof(F)
         d = P @ np.transpose(dminv, (0, 2, 1))
-        # per-vertex gather through the incidence lists, exactly as the kernel's last phase does
-        dz = np.zeros((sp + 1, 3, 3))                                           # LDS order + zero slot
-        dz[perm] = d
-        contrib = np.concatenate([-dz.sum(axis=2)[:, None, :], np.transpose(dz, (0, 2, 1))], axis=1)  # [lds idx, a, xyz]
-        lv_lds = np.zeros((sp + 1, 4), dtype=np.int64)
-        lv_lds[perm] = lv
-        inc, inc_off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
-        assert inc_off[0] == 0 and inc_off[-1] * 4 == len(inc) and np.all(np.diff(inc_off) >= 0)
-        sl, la = inc >> 2, inc & 3
-        real = sl != ZS
-        assert np.all(la[~real] == 1)
-        # every (slot, a) of a real slot appears exactly once, under the right vertex
-        owner = np.repeat(np.arange(T["n_verts"]), 4 * np.diff(inc_off))
-        assert np.array_equal(lv_lds[sl[real], la[real]], owner[real])
-        assert real.sum() == 4 * T["n_slots"]
-        assert len(np.unique(inc[real])) == real.sum()
-        gs = np.zeros((T["n_verts"], 3))
-        np.add.at(gs, owner, contrib[sl, la])
-        ne = T["n_excl"]
-        assert np.all(np.isnan(grad[T["gvid"][:ne]])), "an exclusive vertex was written twice"
-        grad[T["gvid"][:ne]] = gs[:ne] * grad_output
-        rows = sdst[T["stage_off"]:T["stage_off"] + T["n_verts"] - ne]
+        # the force array: entry (v, r) at row_start[r] + v, filled by the slots' scatter, summed row by row per vertex --
+        # exactly the kernel's last two phases
+        contrib = np.concatenate([-d.sum(axis=2)[:, None, :], np.transpose(d, (0, 2, 1))], axis=1)   # [slot, corner a, xyz]: f0 = -(f1 + f2 + f3)
+        rs = T["row_start"].astype(np.int64)
+        nv, nrows = T["n_verts"], T["n_rows"]
+        assert rs[0] == 0 and np.all(np.diff(rs) >= 0) and nrows <= MAX_RANK
+        width = np.diff(rs)
+        assert np.all(width[nrows:] == 0) and (nrows == 0 or width[nrows - 1] > 0) and rs[-1] == 4 * T["n_slots"]
+        assert np.all(np.diff(width[:nrows]) <= 0) and (nrows == 0 or width[0] == nv), "row r = the vertices met by more than r slots"
+        arr = np.full((4 * T["n_slots"], 3), np.nan)
+        ent = rs[rank[real]] + lv[real]                                          # [real slots, 4]
+        assert np.all(lv[real] < width[rank[real]]), "an entry outside its row"
+        assert len(np.unique(ent)) == ent.size == len(arr), "every entry of the force array is written exactly once"
+        arr[ent.reshape(-1)] = contrib[real].reshape(-1, 3)
+        gs = np.zeros((nv, 3))
+        for r in range(nrows):                                                   # rows in order = the kernel's order of additions
+            gs[:width[r]] += arr[rs[r]:rs[r] + width[r]]
+        vd = T["vdst"].astype(np.int64)
+        excl = vd >= 0
+        assert excl.sum() == T["n_excl"] and np.array_equal(vd[excl], T["gvid"][excl])
+        assert np.all(np.isnan(grad[vd[excl]])), "an exclusive vertex was written twice"
+        grad[vd[excl]] = gs[excl] * grad_output
+        rows = ~vd[~excl]
+        assert np.array_equal(rows, sdst[T["stage_off"]:T["stage_off"] + nv - T["n_excl"]]), "vdst and the finish lists disagree"
         assert np.all(np.isnan(stage[rows])), "two tile copies write the same staging row"
-        stage[rows] = gs[ne:]
+        stage[rows] = gs[~excl]
     for k in range(len(vid)):
         rows = stage[off[k]:off[k + 1]]
         assert np.all(np.isnan(grad[vid[k]])), "a finish vertex was also written as exclusive"

@@ -112,7 +112,7 @@ def main():
     import tile_emulator as TE
     sc = scenes.make_scene(args.scene, args.spheres)
     ts = X.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True,
-                      debug_shuffle=2 if args.no_conflict_aware else 0)
+                      debug_flags=2 if args.no_conflict_aware else 0)
     spt = ts.plan_info()["slots_per_thread"]
     tot, slots = {}, 0
     for i, T in enumerate(TE.plan_tiles(ts)):

@@ -27,7 +27,7 @@ def main():
     from tssplat_amd import _capi, scenes, tet_spheres_ext as T
     lib = _capi.load()
     sc = scenes.make_scene(args.scene, args.spheres)
-    ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), debug_shuffle=args.debug_shuffle, max_threads=args.max_threads,
+    ts = T.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), debug_flags=args.debug_shuffle, max_threads=args.max_threads,
                       lds_budget_bytes=args.lds_budget, slots_per_thread=args.spt, rebuild_dminv=bool(args.rebuild_dminv))
     x = torch.from_numpy(scenes.deform(sc, args.sigma)).cuda()
     g = torch.empty_like(x)

@@ -7,6 +7,7 @@ the GPU tests load.
 """
 from __future__ import annotations
 
+import contextlib
 import hashlib
 import os
 import shutil
@@ -19,10 +20,9 @@ LIB = os.path.join(_HERE, "libtssplat_amd.so")
 _OBJ = os.path.join(_HERE, "_obj")
 ARCH = "gfx950"
 
-SOURCES = ["plan.cpp", "conflict_opt.cpp", "stream_plan.cpp", "stream_capi.cpp", "capi.cpp", "kernels.hip", "stream_kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
+SOURCES = ["plan.cpp", "conflict_opt.cpp", "capi.cpp", "kernels.hip", "surface.cpp", "surface_capi.cpp", "surface_kernels.hip",
            "raster_capi.cpp", "raster_kernels.hip", "aa_kernels.hip"]
-HEADERS = ["plan.h", "conflict_opt.h", "stream_plan.h", "stream_kernels.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h"),
-           os.path.join("..", "..", "include", "tssplat_amd_experimental.h")]
+HEADERS = ["plan.h", "conflict_opt.h", "kernels.h", "surface.h", "raster.h", "capi_common.h", os.path.join("..", "..", "include", "tssplat_amd.h")]
 
 HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter", "-pthread"]
 # -fno-slp-vectorize: SLP packs the 3x3 algebra into v_pk_*_f32, which runs at the scalar-fp32 rate on
@@ -85,8 +85,35 @@ def build_variant(name: str, extra_device_flags: list[str]) -> str:
     return out
 
 
+def _write_atomic(path: str, text: str) -> None:
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as fh:
+        fh.write(text)
+    os.replace(tmp, path)
+
+
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time per tree (fcntl lock on a side file): the others wait and then find the stamp up to date."""
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile (if stale) and return the path of libtssplat_amd.so."""
+    stamp = LIB + ".digest"
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == _digest():
+        return LIB
+    with _build_lock():
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     # the stamp sits NEXT TO the library (not under _obj/, which does not travel to the GPU box): a snapshot that carries an
     # up-to-date library is used as it is there instead of being rebuilt by the first import on every fresh box
     stamp = LIB + ".digest"
@@ -107,12 +134,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    link = [hipcc, "-shared", "-o", LIB] + objs + [f"--offload-arch={ARCH}", "-pthread"]
+    # link under a private name and rename: ranks that start together on a fresh box must never map a half-written library
+    tmp = f"{LIB}.{os.getpid()}.tmp"
+    link = [hipcc, "-shared", "-o", tmp] + objs + [f"--offload-arch={ARCH}", "-pthread"]
     if verbose:
         print(" ".join(link), file=sys.stderr)
     subprocess.check_call(link)
-    with open(stamp, "w") as fh:
-        fh.write(digest)
+    os.replace(tmp, LIB)
+    _write_atomic(stamp, digest)
     return LIB
 
 
@@ -129,22 +158,34 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     import torch
     from torch.utils import cpp_extension as ce
     h = hashlib.sha256(open(src, "rb").read())
+    h.update(open(os.path.join(CSRC, "..", "..", "include", "tssplat_amd.h"), "rb").read())   # the entry-point types it hard-codes
     h.update(torch.__version__.encode())
     digest = h.hexdigest()
     if not force and os.path.exists(TORCH_EXT) and os.path.exists(stamp) and open(stamp).read() == digest:
         return TORCH_EXT
+    with _build_lock():
+        if not force and os.path.exists(TORCH_EXT) and os.path.exists(stamp) and open(stamp).read() == digest:
+            return TORCH_EXT
+        return _build_torch_ext_locked(src, stamp, digest, verbose)
+
+
+def _build_torch_ext_locked(src: str, stamp: str, digest: str, verbose: bool) -> str:
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
     os.makedirs(_OBJ, exist_ok=True)
     cxx = os.environ.get("CXX") or shutil.which("g++") or "g++"
     libdir = ce.library_paths()[0]
     cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_tsamd_autograd",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
     cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include", f"-I{sysconfig.get_paths()['include']}"]
-    cmd += [src, "-o", TORCH_EXT, f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", f"-Wl,-rpath,{libdir}"]
+    tmp = f"{TORCH_EXT}.{os.getpid()}.tmp"
+    cmd += [src, "-o", tmp, f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", f"-Wl,-rpath,{libdir}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    with open(stamp, "w") as fh:
-        fh.write(digest)
+    os.replace(tmp, TORCH_EXT)
+    _write_atomic(stamp, digest)
     return TORCH_EXT
 
 

@@ -30,10 +30,10 @@ class Options(C.Structure):
         ("lds_budget_bytes", C.c_int32),
         ("max_threads", C.c_int32),
         ("target_owned", C.c_int32),
-        ("balance_slots", C.c_int32),
+        ("reserved0", C.c_int32),
         ("host_only", C.c_int32),
         ("num_threads", C.c_int32),
-        ("debug_shuffle", C.c_int32),
+        ("debug_flags", C.c_int32),
         ("slots_per_thread", C.c_int32),
         ("rebuild_dminv", C.c_int32),
     ]
@@ -52,33 +52,22 @@ class PlanInfo(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
-class StreamPlanInfo(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in ("n_vertices", "n_tets", "n_components", "n_tubes", "total_slots", "total_bands", "total_pairs",
-                                         "total_chunks", "shared_vertex_copies", "finish_vertices", "device_bytes", "blob_bytes")] + \
-               [(k, C.c_int32) for k in ("max_vertex_slots", "max_bands", "band_slots", "lds_bytes")]
-
-    def as_dict(self) -> dict:
-        return {k: int(getattr(self, k)) for k, _ in self._fields_}
-
-
-class StreamTubeView(C.Structure):
-    _fields_ = [("n_bands", C.c_int32), ("n_vslots", C.c_int32), ("n_owned", C.c_int32), ("n_slots", C.c_int32),
-                ("blob", C.POINTER(C.c_uint8)), ("blob_bytes", C.c_int64), ("slot_tet", C.POINTER(C.c_int32))]
-
-
 class TileView(C.Structure):
     _fields_ = [
         ("n_slots", C.c_int32), ("n_owned", C.c_int32), ("s_pad", C.c_int32), ("n_verts", C.c_int32),
-        ("n_excl", C.c_int32), ("stage_off", C.c_int64), ("n_inc4", C.c_int32),
-        ("planes", C.POINTER(C.c_uint32)), ("inc", C.POINTER(C.c_uint16)), ("inc_off", C.POINTER(C.c_uint16)),
-        ("gvid", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)), ("rest", C.POINTER(C.c_float)),
+        ("n_excl", C.c_int32), ("stage_off", C.c_int64), ("n_rows", C.c_int32), ("rec_base", C.c_int32),
+        ("planes", C.POINTER(C.c_uint32)), ("row_start", C.POINTER(C.c_uint16)),
+        ("gvid", C.POINTER(C.c_int32)), ("vdst", C.POINTER(C.c_int32)), ("slot_tet", C.POINTER(C.c_int32)), ("rest", C.POINTER(C.c_float)),
     ]
 
+
+ABI_VERSION = 2          # include/tssplat_amd.h: TSAMD_ABI_VERSION
 
 # every symbol include/tssplat_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "tsamd_last_error": (C.c_char_p, []),
     "tsamd_version": (C.c_char_p, []),
+    "tsamd_abi_version": (C.c_int32, []),
     "tsamd_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "tsamd_create_with_operator": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.POINTER(Options), C.POINTER(C.c_void_p)]),
@@ -102,8 +91,6 @@ SIGNATURES = {
     "tsamd_graph_launch": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
     "tsamd_graph_destroy": (None, [C.c_void_p]),
     "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
-    "tsamd_debug_set_ablation": (C.c_int, [C.c_void_p, C.c_int]),
-    "tsamd_debug_read_clocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "tsamd_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tsamd_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "tsamd_scale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -111,18 +98,6 @@ SIGNATURES = {
                                         C.c_float, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
     "tsamd_grad_limit_workspace_bytes": (C.c_int64, []),
     "tsamd_grad_limit": (C.c_int, [C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
-    # streaming tiles (experimental)
-    "tsamd_stream_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
-    "tsamd_stream_destroy": (None, [C.c_void_p]),
-    "tsamd_stream_info": (C.c_int, [C.c_void_p, C.POINTER(StreamPlanInfo)]),
-    "tsamd_stream_get_tube": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(StreamTubeView)]),
-    "tsamd_stream_get_finish_lists": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_int32)),
-                                                C.POINTER(C.POINTER(C.c_int32))]),
-    "tsamd_stream_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
-                                                C.c_void_p]),
-    "tsamd_stream_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
-    "tsamd_stream_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
-    "tsamd_stream_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "tsamd_train_loop_workspace_bytes": (C.c_int64, [C.c_int32]),
     "tsamd_train_loop_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                           C.POINTER(C.c_void_p)]),
@@ -193,6 +168,9 @@ def load(build_if_missing: bool = True):
         fn = getattr(lib, name)       # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    if lib.tsamd_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.tsamd_abi_version()}, these bindings are written for {ABI_VERSION} "
+                          "(include/tssplat_amd.h: TSAMD_ABI_VERSION) -- rebuild the library")
     _lib = lib
     return lib
 
@@ -240,7 +218,6 @@ def make_options(**kw) -> Options:
     o = Options()
     o.struct_size = C.sizeof(Options)
     o.device = -1
-    o.balance_slots = 1
     for k, v in kw.items():
         if not hasattr(o, k):
             raise TypeError(f"unknown tsamd option {k!r}")

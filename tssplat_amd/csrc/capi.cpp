@@ -6,7 +6,7 @@
 // tiling plan's planes, the staging rows for shared vertices and the per-tile
 // energy partials.  Unlike the reference destructor (tet_spheres.cpp:128-138)
 // everything allocated is freed.
-#include "../../include/tssplat_amd_experimental.h"   // (includes tssplat_amd.h)
+#include "../../include/tssplat_amd.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -49,14 +49,12 @@ struct tsamd_handle {
     // device
     tsamd::TileDesc *d_tiles = nullptr;
     uint8_t *d_blob = nullptr;
-    int32_t *d_gvid = nullptr, *d_fin_vid = nullptr, *d_fin_off = nullptr, *d_fin_idx = nullptr;
+    int32_t *d_gvid = nullptr, *d_vdst = nullptr, *d_fin_vid = nullptr, *d_fin_off = nullptr;
     float *d_stage = nullptr;
     double *d_partials = nullptr;
     double *d_terms = nullptr;
     float *d_energy_scratch = nullptr;
     // optional kernel timing (bench.py roofline leg)
-    int dbg = 0;  // kernel ablation switches, tools/ablate.py only
-    long long *d_clk = nullptr;  // 16 clock stamps per tile (ablation builds)
     bool timing = false;
     std::vector<hipEvent_t> events;  // 3 per recorded evaluation
 };
@@ -89,12 +87,11 @@ void release(tsamd_handle *h)
         (void)hipFree(h->d_gvid);
         (void)hipFree(h->d_fin_vid);
         (void)hipFree(h->d_fin_off);
-        (void)hipFree(h->d_fin_idx);
+        (void)hipFree(h->d_vdst);
         (void)hipFree(h->d_stage);
         (void)hipFree(h->d_partials);
         (void)hipFree(h->d_terms);
         (void)hipFree(h->d_energy_scratch);
-        (void)hipFree(h->d_clk);
         for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     }
     delete h;
@@ -121,17 +118,16 @@ int to_device(tsamd_handle *h, int device)
     if ((rc = upload(h->d_tiles, P.tiles.data(), P.tiles.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(P.blob.data()), P.blob.size() * 4, h->device_bytes))) return rc;
     if ((rc = upload(h->d_gvid, P.gvid.data(), P.gvid.size(), h->device_bytes))) return rc;
+    if ((rc = upload(h->d_vdst, P.vdst.data(), P.vdst.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_fin_vid, P.fin_vid.data(), P.fin_vid.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_fin_off, P.fin_off.data(), P.fin_off.size(), h->device_bytes))) return rc;
-    if ((rc = upload(h->d_fin_idx, P.fin_idx.data(), P.fin_idx.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_stage, nullptr, size_t(P.n_stage) * 3, h->device_bytes))) return rc;
     if ((rc = upload(h->d_partials, nullptr, P.tiles.size() * 2, h->device_bytes))) return rc;
     if ((rc = upload(h->d_terms, nullptr, 2, h->device_bytes))) return rc;
     if ((rc = upload(h->d_energy_scratch, nullptr, 1, h->device_bytes))) return rc;
     TSAMD_HIP(hipMemset(h->d_terms, 0, 2 * sizeof(double)));
     {
-        const int32_t lds_p = int32_t(tsamd::tile_lds_bytes((P.max_slots + 3) & ~3, P.max_verts, P.n_planes == tsamd::kPlanesRebuild));
-        const hipError_t ce = tsamd::configure_kernels(std::max(P.lds_bytes, lds_p <= 160 * 1024 ? lds_p : P.lds_bytes));
+        const hipError_t ce = tsamd::configure_kernels(P.lds_bytes);
         if (ce == hipErrorInvalidDeviceFunction)
             return fail(TSAMD_ERR_HIP, "a tile kernel of this build has a static LDS object: its dynamic LDS array no longer starts at LDS "
                                        "address 0, which the kernels' absolute LDS addressing relies on (kernels.hip: lds_at)");
@@ -148,7 +144,6 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     tsamd_options opt;
     std::memset(&opt, 0, sizeof(opt));
     opt.device = -1;
-    opt.balance_slots = 1;
     if (o) {
         if (o->struct_size != int32_t(sizeof(tsamd_options)))
             return fail(TSAMD_ERR_INVALID_ARGUMENT, "tsamd_options.struct_size does not match this library");
@@ -158,12 +153,18 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     if (opt.lds_budget_bytes > 0) po.lds_budget = opt.lds_budget_bytes;
     if (opt.max_threads > 0) po.max_threads = opt.max_threads;
     po.target_owned = opt.target_owned;
-    po.balance = opt.balance_slots;
     po.num_threads = opt.num_threads;
-    po.shuffle = opt.debug_shuffle & 1;
-    po.conflict_aware = (opt.debug_shuffle & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware ordering off
-    if (opt.slots_per_thread != 0 && opt.slots_per_thread != tsamd::kSlotsPerLane)
-        return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread must be 0 or 2 (the 4-slot kernels were removed: they spilled and measured 25-45 % slower)");
+    po.conflict_aware = (opt.debug_flags & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware neighbour ordering off
+    {
+        const int spt = opt.slots_per_thread != 0 ? opt.slots_per_thread : tsamd::kSlotsPerLane;
+        if (spt < 2 || spt > 4) return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread must be 0, 2, 3 or 4");
+        if (!tsamd::lane_layout_supported(spt, opt.max_threads > 0 ? opt.max_threads : tsamd::kTileThreads))
+            return fail(TSAMD_ERR_INVALID_ARGUMENT, "max_threads exceeds what the tile kernels are compiled for at " + std::to_string(spt) +
+                                                        " slots per thread (2: 768, 3: 1024, 4: 768)");
+        if (spt != tsamd::kSlotsPerLane && (op || opt.rebuild_dminv))
+            return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread 3 and 4 are built for the built-in operator with streamed Dm^-1 only");
+        po.slots_per_lane = spt;
+    }
     po.rebuild_dminv = opt.rebuild_dminv ? 1 : 0;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
@@ -223,9 +224,9 @@ tsamd::EvalArgs eval_args(tsamd_handle *h, const float *x, const float *grad_out
     a.tiles = h->d_tiles;
     a.blob = h->d_blob;
     a.gvid = h->d_gvid;
+    a.vdst = h->d_vdst;
     a.fin_vid = h->d_fin_vid;
     a.fin_off = h->d_fin_off;
-    a.fin_idx = h->d_fin_idx;
     a.n_tiles = int64_t(h->plan.tiles.size());
     a.n_finish = int64_t(h->plan.fin_vid.size());
     a.block_threads = h->plan.block_threads;
@@ -234,8 +235,7 @@ tsamd::EvalArgs eval_args(tsamd_handle *h, const float *x, const float *grad_out
     a.weighted = h->plan.n_planes == tsamd::kPlanesWeighted || h->plan.n_planes == tsamd::kPlanesWeightedSym;
     a.n_planes = h->plan.n_planes;
     a.rebuild = h->plan.n_planes == tsamd::kPlanesRebuild;
-    a.dbg = h->dbg;
-    a.clk = h->d_clk;
+    a.spt = h->plan.spt;
     a.x = x;
     a.grad_out = grad_out;
     a.c1 = c1;
@@ -274,7 +274,8 @@ int evaluate(tsamd_handle *h, const float *x, const float *grad_out, float c1, f
 extern "C" {
 
 const char *tsamd_last_error(void) { return g_err.c_str(); }
-const char *tsamd_version(void) { return "tssplat_amd 0.1 (gfx950)"; }
+const char *tsamd_version(void) { return "tssplat_amd 0.2 (gfx950)"; }
+int32_t tsamd_abi_version(void) { return TSAMD_ABI_VERSION; }
 
 int tsamd_create(const float *rest_xyz, int64_t n_vertices, const int32_t *tets, int64_t n_tets,
                  const tsamd_options *options, tsamd_handle **out)
@@ -342,15 +343,15 @@ int tsamd_get_tile(const tsamd_handle *h, int64_t tile, tsamd_tile_view *out)
     out->n_verts = d.n_verts;
     out->n_excl = d.n_excl;
     out->stage_off = d.stage_off;
-    out->n_inc4 = d.n_inc4;
+    out->n_rows = d.n_rows;
+    out->rec_base = d.rec_base;
     out->planes = P.blob.data() + d.blob_off / 4;
-    out->inc = reinterpret_cast<const uint16_t *>(out->planes + size_t(P.n_planes) * size_t(d.s_pad));
-    out->inc_off = out->inc + 4 * size_t(d.n_inc4);
+    out->row_start = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(out->planes) + tsamd::tile_rowtab_offset(P.n_planes, d.s_pad));
     out->gvid = P.gvid.data() + d.vert_off;
+    out->vdst = P.vdst.data() + d.vert_off;
     out->slot_tet = P.slot_tet.data() + P.slot_base[size_t(tile)];
     out->rest = P.n_planes == tsamd::kPlanesRebuild
-                    ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(out->planes) +
-                                                      tsamd::tile_rest_offset(P.n_planes, d.s_pad, d.n_inc4, d.n_verts))
+                    ? reinterpret_cast<const float *>(reinterpret_cast<const uint8_t *>(out->planes) + tsamd::tile_rest_offset(P.n_planes, d.s_pad))
                     : nullptr;
     return TSAMD_OK;
 }
@@ -521,35 +522,6 @@ int tsamd_read_energy_terms(tsamd_handle *h, void *stream, double *terms_host2)
     TSAMD_HIP(hipMemcpyAsync(terms_host2, h->d_terms, 2 * sizeof(double), hipMemcpyDeviceToHost,
                              static_cast<hipStream_t>(stream)));
     TSAMD_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    return TSAMD_OK;
-}
-
-int tsamd_debug_set_ablation(tsamd_handle *h, int flags)
-{
-    if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "handle is null");
-#ifndef TSAMD_ABLATION
-    if (flags) return fail(TSAMD_ERR_INVALID_ARGUMENT, "this build has no ablation switches (compile with -DTSAMD_ABLATION)");
-#endif
-    h->dbg = flags;
-    return TSAMD_OK;
-}
-
-int tsamd_debug_read_clocks(tsamd_handle *h, long long *host_out, int64_t capacity)
-{
-    if (!h || !host_out) return fail(TSAMD_ERR_INVALID_ARGUMENT, "null argument");
-    if (h->host_only) return fail(TSAMD_ERR_HOST_ONLY, "handle was created host_only; no device path");
-    const int64_t need = int64_t(h->plan.tiles.size()) * 256;
-    if (capacity < need) return fail(TSAMD_ERR_INVALID_ARGUMENT, "capacity too small: need 256 entries (16 waves x 16 stamps) per tile");
-    DeviceGuard g;
-    TSAMD_HIP(g.enter(h->device));
-    if (!h->d_clk) {   // first call arms the stamps; the next evaluation fills them
-        TSAMD_HIP(hipMalloc(reinterpret_cast<void **>(&h->d_clk), size_t(need) * sizeof(long long)));
-        TSAMD_HIP(hipMemset(h->d_clk, 0, size_t(need) * sizeof(long long)));
-        std::memset(host_out, 0, size_t(need) * sizeof(long long));
-        return TSAMD_OK;
-    }
-    TSAMD_HIP(hipDeviceSynchronize());
-    TSAMD_HIP(hipMemcpy(host_out, h->d_clk, size_t(need) * sizeof(long long), hipMemcpyDeviceToHost));
     return TSAMD_OK;
 }
 

@@ -5,7 +5,7 @@
 
 #include <string>
 
-#include "../../include/tssplat_amd_experimental.h"   // (includes tssplat_amd.h)
+#include "../../include/tssplat_amd.h"
 
 namespace tsamd {
 

@@ -13,16 +13,15 @@ struct EvalArgs {
     // plan, resident in HBM
     const TileDesc *tiles;
     const uint8_t *blob;
-    const int32_t *gvid;
-    const int32_t *fin_vid, *fin_off, *fin_idx;
+    const int32_t *gvid, *vdst;
+    const int32_t *fin_vid, *fin_off;
     int64_t n_tiles, n_finish;
     int32_t block_threads, lds_bytes;
     int32_t vert_stride = 0;      // gvid entries per tile (Plan::vert_stride)
     bool rebuild = false;         // the plan keeps rest positions instead of the Dm^-1 planes (kPlanesRebuild)
     bool weighted = false;        // the plan carries an explicit element operator (22 planes per slot; 18 when it is symmetric)
     int32_t n_planes = 13;        // dword planes per slot of this plan (where a tile's incidence list starts)
-    int dbg = 0;            // ablation switches (tools/ablate.py); 0 in production
-    long long *clk = nullptr;  // ablation builds: per-tile phase clock stamps
+    int32_t spt = kSlotsPerLane;  // slots per lane the plan is laid out for (selects the kernel instantiation)
     // per evaluation
     const float *x;
     const float *grad_out;  // device scalar or nullptr
@@ -57,13 +56,12 @@ struct TrainLoopStep {
 hipError_t train_loop_create(const EvalArgs &e, float *param, float *g1, float *g2, int64_t n_param, void *ws, int n_iters, TrainLoopGraph **out);
 hipError_t train_loop_launch(TrainLoopGraph *g, const TrainLoopStep *steps, float lr, float b1, float b2, hipStream_t stream);
 void train_loop_destroy(TrainLoopGraph *g);
-hipError_t launch_finish(const int32_t *fin_vid, const int32_t *fin_off, int64_t n_finish, const float *stage, float *grad,
-                         const float *grad_out, const double *partials, int64_t n_partials, float c1, float c2, float *energy,
-                         double *terms, hipStream_t stream);
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream);
 hipError_t launch_grad_limit(float *grad, int64_t n, float thr, float s, void *workspace, hipStream_t stream);
 hipError_t launch_adam_uniform(float *p, const float *grad, float *g1, float *g2, int64_t n, float lr, float b1, float b2,
                                float bias1, float bias2, float limit, void *workspace, hipStream_t stream);
 hipError_t configure_kernels(int lds_bytes);
+// is there a tile kernel for `spt` slots per lane and workgroups of up to `max_threads` threads?
+bool lane_layout_supported(int spt, int max_threads);
 
 }  // namespace tsamd

@@ -1,21 +1,21 @@
 // gfx950 (MI355X / CDNA4) kernels for the tet-sphere geometry energy.
 //
 // One workgroup evaluates one *tile*: a cluster of tets (owned + one-ring face halo; ~1 500 slots at the default
-// 768 threads x 2 slots per lane and <= 80 KiB of LDS, two workgroups per CU; up to 2 728 slots with one 160 KiB
-// workgroup) whose deformation gradients F fit the LDS.  Per evaluation the tile's dword planes (16-bit local
-// vertex offsets, 15-bit record tokens of the face neighbours, fp32 Dm^-1: 13 planes = 52 B per slot; 22 with an
-// explicit element operator, 4 with rebuild_dminv -- plan.h) stream from HBM exactly once, coalesced; F, L F,
-// L^T L F and the vertex accumulation never leave the CU.  No MFMA: 3x3 algebra at ~4 flop/B; the kernel is bound
-// by VALU issue + LDS data movement per slot, not by HBM (profiles/r02_experiments.md).
+// 768 threads x 2 slots per lane and <= 80 KiB of LDS, two workgroups per CU) whose deformation gradients F fit
+// the LDS.  Per evaluation the tile's dword planes (10-bit local vertices + 6-bit ranks, 16-bit record tokens of the
+// face neighbours, fp32 Dm^-1: 13 planes = 52 B per slot; 22 with an explicit element operator, 4 with
+// rebuild_dminv -- plan.h) stream from HBM exactly once, coalesced; F, L F, L^T L F and the vertex accumulation
+// never leave the CU.  No MFMA: 3x3 algebra at ~4 flop/B.
 //
 // What each stage stands for in the reference
 // (/root/reference/tssplat_ext/tet_spheres/tet_spheres_cuda.cu):
 //   pass 1  F = Ds Dm^-1, det, penalty     <- cusparseSpMV(G,x) :167,:221 + cuda_forward_det :48-66
 //   pass 2  H = L F, 1/2|H|^2              <- cusparseSpMV(GTLTLG,x) :131 + cublasSdot :154 (factored, no M)
 //   pass 3  P = c1 L^T H + c2 dpen cof(F)  <- cusparseSpMV(GTLTLG,x) :216 + cuda_backward_det :68-102
-//           d = P Dm^-T, per-vertex gather <- cusparseSpMV(TRANSPOSE, G) :248 (their transposed COO SpMV
+//           d = P Dm^-T, per-vertex sums   <- cusparseSpMV(TRANSPOSE, G) :248 (their transposed COO SpMV
 //                                             scatters with atomics; LDS f32 atomics measured ~3 clk/lane
-//                                             on gfx950, so each vertex sums its incident tets instead)
+//                                             on gfx950, so each slot writes its four corner forces to plan-assigned
+//                                             entries of a per-vertex array and a lane per vertex adds them up)
 //   finish  sum shared-vertex partials, reduce energy, * grad_out
 //                                          <- cublasSasum :185, host combine :191, cublasSscal :258
 // There is no host synchronisation anywhere (the reference blocks three times
@@ -31,13 +31,9 @@ namespace {
 
 constexpr int kWave = 64;
 
-// Scheduling fence between the slots (2 or 4) a lane processes in a pass (build with -DTSAMD_NO_SLOT_FENCE to let
-// the compiler interleave them: measured +0.1 %).
-#ifdef TSAMD_NO_SLOT_FENCE
-#define SLOT_FENCE() ((void)0)
-#else
+// Scheduling fence between the slots a lane processes in a pass: one slot's gathers in flight at a time (VGPR budget;
+// letting the compiler interleave them measured +0.1 %).
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
@@ -74,15 +70,28 @@ __device__ __forceinline__ GLOBAL_AS T *as_global(T *p)
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// F of one slot from the staged positions (byte offsets o0..o3 into xs) and the slot's Dm^-1.
-// xs holds (x, y, z, 0); reading it as 4 x u32 behind an asm fence keeps the compiler from
+// LDS accesses by absolute byte address.  The kernels' only LDS object is the dynamic array, which starts at LDS
+// address 0 as long as a kernel has no static LDS object: configure_kernels() checks exactly that for every tile
+// kernel instantiation (hipFuncGetAttributes: sharedSizeBytes == 0) and refuses to run otherwise (a device-side check
+// in the prologue costs 26 VGPRs, see profiles/r02_experiments.md); addressing it as `smem + offset` makes the compiler add the array's link-time
+// address -- a literal 0 -- to every computed offset: one wasted VALU instruction per access in a kernel that is
+// bound by instruction issue.
+#define LDS_AS __attribute__((address_space(3)))
+template <class T>
+__device__ __forceinline__ LDS_AS T *lds_at(uint32_t byte_addr)
+{
+    return (LDS_AS T *)(uintptr_t)byte_addr;
+}
+
+// F of one slot from the staged positions (byte offsets o0..o3 behind LDS address xs) and the slot's Dm^-1.
+// The staging area holds (x, y, z, 0); reading it as 4 x u32 behind an asm fence keeps the compiler from
 // narrowing the access to ds_read_b96, which costs 8 LDS cycles against 4 for ds_read_b128.
 template <class VF>
-__device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+__device__ __forceinline__ void slot_F(uint32_t xs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
                                        const VF *dm, int p, float *F)
 {
-    const v4u r0 = *reinterpret_cast<const v4u *>(xs + o0), r1 = *reinterpret_cast<const v4u *>(xs + o1),
-              r2 = *reinterpret_cast<const v4u *>(xs + o2), r3 = *reinterpret_cast<const v4u *>(xs + o3);
+    const v4u r0 = *lds_at<const v4u>(xs + o0), r1 = *lds_at<const v4u>(xs + o1),
+              r2 = *lds_at<const v4u>(xs + o2), r3 = *lds_at<const v4u>(xs + o3);
     asm volatile("" : : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
     const float3 x0 = make_float3(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z));
     const float3 x1 = make_float3(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z));
@@ -101,11 +110,11 @@ __device__ __forceinline__ void slot_F(const unsigned char *xs, uint32_t o0, uin
 // edges x1-x0, x2-x0, x3-x0 as columns, its inverse is cofactor^T / det -- the formula plan.cpp evaluates in double
 // for the streamed planes, here in fp32 (1 / det through v_rcp_f32 and one Newton step).  dm[3 i + k][p] = Dm^-1[i][k].
 template <class VF>
-__device__ __forceinline__ void rebuild_dminv(const unsigned char *rs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
+__device__ __forceinline__ void rebuild_dminv(uint32_t rs, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3,
                                               VF *dm, int p)
 {
-    const v4u r0 = *reinterpret_cast<const v4u *>(rs + o0), r1 = *reinterpret_cast<const v4u *>(rs + o1),
-              r2 = *reinterpret_cast<const v4u *>(rs + o2), r3 = *reinterpret_cast<const v4u *>(rs + o3);
+    const v4u r0 = *lds_at<const v4u>(rs + o0), r1 = *lds_at<const v4u>(rs + o1),
+              r2 = *lds_at<const v4u>(rs + o2), r3 = *lds_at<const v4u>(rs + o3);
     asm volatile("" : : "v"(r0), "v"(r1), "v"(r2), "v"(r3));
     const float x0 = __uint_as_float(r0.x), y0 = __uint_as_float(r0.y), z0 = __uint_as_float(r0.z);
     // D[3 i + k] = coordinate i of edge k
@@ -136,22 +145,9 @@ struct Mat9 {
     float p8;
 };
 
-// LDS accesses by absolute byte address.  The kernels' only LDS object is the dynamic array, which starts at LDS
-// address 0 as long as a kernel has no static LDS object: configure_kernels() checks exactly that for every tile
-// kernel instantiation (hipFuncGetAttributes: sharedSizeBytes == 0) and refuses to run otherwise (a device-side check
-// in the prologue costs 26 VGPRs, see profiles/r02_experiments.md); addressing it as `smem + offset` makes the compiler add the array's link-time
-// address -- a literal 0 -- to every computed offset: one wasted VALU instruction per access in a kernel that is
-// bound by instruction issue.
-#define LDS_AS __attribute__((address_space(3)))
-template <class T>
-__device__ __forceinline__ LDS_AS T *lds_at(uint32_t byte_addr)
-{
-    return (LDS_AS T *)(uintptr_t)byte_addr;
-}
-
 __device__ __forceinline__ uint32_t own_token_addr(uint32_t idx) { return 48u * idx + ((idx >> 1) & 12u); }
 
-__device__ __forceinline__ Mat9 load_slot(const unsigned char *, uint32_t t)
+__device__ __forceinline__ Mat9 load_slot(uint32_t t)
 {
     const uint32_t s = t & ~15u;
     const v4f a = *lds_at<const v4f>(s + 16), b = *lds_at<const v4f>(s + 32);
@@ -162,7 +158,7 @@ __device__ __forceinline__ Mat9 load_slot(const unsigned char *, uint32_t t)
 }
 
 // Stores cost 2 cycles per source dword on the VGPR -> LDS path, so the tail goes out as one dword, not a quad.
-__device__ __forceinline__ void store_slot(unsigned char *, uint32_t t, const float *m)
+__device__ __forceinline__ void store_slot(uint32_t t, const float *m)
 {
     const uint32_t s = t & ~15u;
     *lds_at<v4f>(s + 16) = v4f{m[0], m[1], m[2], m[3]};
@@ -186,30 +182,16 @@ __device__ __forceinline__ Mat9 mat9_of(const float *m)
     return r;
 }
 
-__device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 acc, const uint32_t *nb
-#ifdef TSAMD_EXP_PARTNER   // experiment (wrong results): neighbour 0 taken from registers -- what a lane-local face partner would save
-                                               , const Mat9 &partner
-#endif
-)
+__device__ __forceinline__ Mat9 laplace_gather(Mat9 acc, const uint32_t *nb)
 {
-#ifdef TSAMD_PRIO   // experiment: waves that are issuing gathers win the arbitration against waves doing algebra
-    __builtin_amdgcn_s_setprio(TSAMD_PRIO);
-#endif
-#ifdef TSAMD_EXP_PARTNER
-    Mat9 g0 = partner;
-#else
-    Mat9 g0 = load_slot(lds, nb[0]);
-#endif
+    Mat9 g0 = load_slot(nb[0]);
     acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
     acc.p8 *= 4.f;
-    Mat9 g1 = load_slot(lds, nb[1]);
+    Mat9 g1 = load_slot(nb[1]);
     sub9(acc, g0);
-    g0 = load_slot(lds, nb[2]);
+    g0 = load_slot(nb[2]);
     sub9(acc, g1);
-    g1 = load_slot(lds, nb[3]);
-#ifdef TSAMD_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
+    g1 = load_slot(nb[3]);
     sub9(acc, g0);
     sub9(acc, g1);
     return acc;
@@ -217,15 +199,14 @@ __device__ __forceinline__ Mat9 laplace_gather(const unsigned char *lds, Mat9 ac
 
 // explicit element operator: acc = dg * own + sum_k w[k] * neighbour_k  (the weights carry their sign; 0 for a
 // face that points at the slot itself)
-__device__ __forceinline__ Mat9 operator_gather(const unsigned char *lds, const Mat9 &own, float dg, const float *w,
-                                                const uint32_t *nb)
+__device__ __forceinline__ Mat9 operator_gather(const Mat9 &own, float dg, const float *w, const uint32_t *nb)
 {
     Mat9 acc;
     acc.p01 = own.p01 * dg; acc.p23 = own.p23 * dg; acc.p45 = own.p45 * dg; acc.p67 = own.p67 * dg;
     acc.p8 = own.p8 * dg;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const Mat9 g = load_slot(lds, nb[k]);
+        const Mat9 g = load_slot(nb[k]);
         acc.p01 += g.p01 * w[k]; acc.p23 += g.p23 * w[k]; acc.p45 += g.p45 * w[k]; acc.p67 += g.p67 * w[k];
         acc.p8 += g.p8 * w[k];
     }
@@ -273,7 +254,7 @@ struct KernelArgs {
     const TileDesc *tiles;
     const uint8_t *blob;
     const int32_t *gvid;
-    const int32_t *sdst;  // staging row of every shared tile-vertex copy
+    const int32_t *vdst;  // per tile vertex: >= 0 row of grad, < 0 staging row ~vdst (plan.h)
     const float *x;
     const float *grad_out;
     float *grad;
@@ -284,55 +265,28 @@ struct KernelArgs {
     int order;
     int n_tiles;
     int tiles_per_xcd;
-    int vert_stride;   // gvid entries per tile: tile t's vertex ids start at t * vert_stride (= its descriptor's vert_off)
+    int vert_stride;   // gvid / vdst entries per tile: tile t's vertex ids start at t * vert_stride (= its descriptor's vert_off)
     int n_planes;      // dword planes per slot (explicit-operator plans: 22, or 18 for a symmetric operator -- plan.h)
-    int dbg;  // ablation switches, honoured only by -DTSAMD_ABLATION builds (tools/ablate.py)
-    long long *clk;  // ablation builds: 16 shader-clock stamps per wave (up to 16 waves) per tile
 };
 
-enum : int { DBG_LOCAL_GATHER3 = 2, DBG_LOCAL_GATHER2 = 4, DBG_SKIP_P3 = 8, DBG_SKIP_P2 = 16,
-             DBG_EXIT_AFTER_P1 = 32, DBG_EXIT_AFTER_LOAD = 64, DBG_SKIP_VGATHER = 128, DBG_SKIP_OUT = 256, DBG_STORE_LOCAL = 512 };
+constexpr uint32_t kXS = kRowTabBytes;   // LDS byte address of the staged positions (plan.h: LDS map of a tile)
 
-#ifdef TSAMD_ABLATION
-#define DBG(flag) ((a.dbg & (flag)) != 0)
-#define STAMP(k)                                                          \
-    do {                                                                  \
-        if (a.clk && (threadIdx.x & 63) == 0) a.clk[(16 * size_t(tile) + (threadIdx.x >> 6)) * 16 + (k)] = clock64(); \
-    } while (0)
-#elif defined(TSAMD_STAMPS)      // the production kernel + the shader-clock stamps, no switches (tools/ablate.py --stamps-only)
-#define DBG(flag) false
-#define STAMP(k)                                                          \
-    do {                                                                  \
-        if (a.clk && (threadIdx.x & 63) == 0) a.clk[(16 * size_t(tile) + (threadIdx.x >> 6)) * 16 + (k)] = clock64(); \
-    } while (0)
-#elif defined(TSAMD_FORCE_DBG)   // pricing builds: an ablation switch as a compile-time constant, no stamps (tools/ab_variants.py)
-#define DBG(flag) (((TSAMD_FORCE_DBG) & (flag)) != 0)
-#define STAMP(k) ((void)0)
-#else
-#define DBG(flag) false
-#define STAMP(k) ((void)0)
-#endif
+// byte offset (16 v) of a corner's staged position from its 16-bit vertex field (low / high half of a plane dword)
+__device__ __forceinline__ uint32_t pos_lo(uint32_t w) { return (w & kVertMask) << 4; }
+__device__ __forceinline__ uint32_t pos_hi(uint32_t w) { return ((w >> 16) & kVertMask) << 4; }
 
-// One workgroup = one tile.  LDS map (SA = s_pad + 4 slots incl. the all-zero slot at index s_pad,
-// VP = vertices rounded up to 4):
-//   [0, 48 SA)        one 48 B record per slot, addressed by lds_index(slot): F (9 floats + pad),
-//                     overwritten by H after pass 2, overwritten by the 4 x 3 vertex forces after pass 3
-//   [48 SA, +16 VP)   xs: float4 per local vertex (staged positions)
-//   then 256 B of reduction scratch (the per-wave energy sums, written behind the H stores, added up after the next
-//   barrier by the last wave -- a tile ends with its vertex stores, there is no reduction phase at the end).
-// The passes are separated by six workgroup barriers: staged positions | F | (F reads done) H | H | (H reads done) forces | gather.
-// Lane t's p-th slot lives at index p * nq + t, so a wave's own-slot accesses walk consecutive
-// 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns).
-// Two slots per lane (kSlotsPerLane; the plan is laid out for it); launch bounds <768 threads, 6 waves per SIMD> give the
-// 80-VGPR budget at which two workgroups share a CU.  (Round 2 also carried 4-slots-per-lane and 1024-thread
-// builds: they spilled or ran one workgroup per CU, measured 25-45 % slower, and were removed in round 3.)
-// Everything one workgroup does for one tile.  (Resident workgroups walking several tiles with next-tile
-// prefetch, and touching a successor tile's planes / descriptor / vertex ids into L2, were measured slower or
-// within noise: DESIGN.md section 4.)
-template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD>
-__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, const int SA, const int VP, int32_t gv0)
+// One workgroup = one tile.  LDS map (plan.h): row table at 0, staged positions at kXS, reduction scratch, then at
+// td.rec_base one 48 B record per slot: F (9 floats + pad), overwritten by H after pass 2; after pass 3 the same bytes hold
+// the tile's force array, 12 bytes per (vertex, slot) incidence, row r = the r-th slot of every vertex that has one.
+// The passes are separated by six workgroup barriers: staged positions | F | (F reads done) H | H | (H reads done) forces | sums.
+// Lane t's p-th slot is item p * nq + t and lives at record index p * nq + t, so a wave's own-slot accesses walk consecutive
+// 48 B records (conflict-free for 16 B accesses: 12 l mod 64 is a permutation of the 4-dword columns); the items below
+// n_owned are the owned ones.
+// SPT slots per lane (the plan is laid out for it); the default, two, with launch bounds <768 threads, 6 waves per SIMD> gives
+// the 80-VGPR budget at which two workgroups share a CU.
+template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD, int SPT>
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, int32_t gv0)
 {
-    constexpr int SPT = kSlotsPerLane;
     // named here, not passed in: a pointer parameter would be a generic pointer and every LDS access of the
     // out-of-line copy would turn into a flat_* instruction
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -340,75 +294,51 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     typedef float VF __attribute__((ext_vector_type(SPT)));
     static_assert(!(REBUILD && WEIGHTED), "rebuild_dminv is built for the built-in operator");
     // A slot's own F stays in registers from pass 1 to pass 2, and its own H from pass 2 to pass 3, instead of being read
-    // back from LDS (F: -8 LDS cycles per 64 slots, tile kernel -0.9 %, round 2; H: spilled in round 2, fits since the
-    // pruned build -- 78 VGPRs, no scratch -- tile kernel 0.4325 -> 0.4310 ms).  The explicit-operator build reads both back
-    // (its weights take the registers).
-#ifdef TSAMD_KEEP_OWN
-    constexpr int kKeepF = TSAMD_KEEP_OWN & 1 ? SPT : 0, kKeepH = TSAMD_KEEP_OWN & 2 ? SPT : (TSAMD_KEEP_OWN & 4 ? 1 : 0);
-#else
+    // back from LDS.  The explicit-operator build reads both back (its weights take the registers).
     constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;
-#endif
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
     const auto g_blob = as_global(a.blob);
     const auto g_gvid = as_global(a.gvid);
-    const auto g_sdst = as_global(a.sdst);
+    const auto g_vdst = as_global(a.vdst);
     const auto g_x = as_global(a.x);
     const auto g_grad = as_global(a.grad);
     const auto g_stage = as_global(a.stage);
     const auto g_partials = as_global(a.partials);
-    unsigned char *xs = smem + 48 * SA;
-    double *red = reinterpret_cast<double *>(xs + (REBUILD ? 32 : 16) * VP);
+    const uint32_t VP = uint32_t(td.n_verts + 3) & ~3u;
+    const uint32_t RS = kXS + 16u * VP;                         // staged rest positions (rebuild_dminv plans)
+    const uint32_t RB = uint32_t(td.rec_base);                  // record 0
+    LDS_AS double *red = lds_at<double>(RB - 256u);
     const int nq = td.s_pad / SPT;
-    const uint32_t ZS = uint32_t(td.s_pad);
     const bool active = tid < nq;
-    const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);  // 13 planes of s_pad dwords
-    // (non-temporal loads of the planes were measured: tile kernel +1.4 %, finish kernel -4 %, net slower)
+    const GLOBAL_AS uint32_t *pl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);  // the planes, s_pad dwords each
     // lanes beyond the tile read lane 0's entries (and never use them): with every load unconditional the stream
     // is straight-line code and the compiler can count its waits (vmcnt(13)) instead of draining to vmcnt(0)
     const int lt = active ? tid : 0;
     auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * lt); };
     auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * lt); };
-    STAMP(0);
-#ifdef TSAMD_SLEEP_BODY   // pipeline-model probe: idle cycles at the head of the tile body (descriptor requested, no plane load issued yet)
-    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_BODY);
-#endif
-    // The position gather is a chain of two dependent loads (vertex id, then x).  vmcnt retires in order, so the
-    // id load goes out FIRST: the wait for it then does not include the 13 plane loads, and the x loads travel
-    // together with the planes instead of behind them.
-#ifdef TSAMD_LATE_GVID   // round-2 form: address from the descriptor (one more dependent memory latency at the head of a tile)
-    gv0 = g_gvid[td.vert_off + (tid < td.n_verts ? tid : 0)];
-#endif
-    // (otherwise the id was requested by the kernel's first instructions, ahead of the descriptor fetch -- see there)
-#ifndef TSAMD_OLD_LOAD_ORDER
     // ---- stream the tile ----
-    // A CU pulls cold data at ~11 bytes per cycle whatever the rest of the chip does (tools/ubench_ingest.hip: one workgroup
-    // alone gets 10-12 B/cycle, two on a CU share the same 11), in the order the loads were issued, wave after wave.  The
-    // order below is built around that FIFO:
-    //   1. (kernel entry) the vertex ids;  2. the two vertex-offset planes -- 12 KB per workgroup, about what the id's latency covers;
-    //   3. the positions, as soon as the ids are back: they reach the LDS behind 12 KB instead of behind the whole 80 KB, so the
+    // A CU pulls cold data at ~11 bytes per cycle whatever the rest of the chip does (tools/ubench_ingest.hip), in the order the
+    // loads were issued, wave after wave.  The order below is built around that FIFO:
+    //   1. (kernel entry) the vertex ids;  2. the two vertex planes -- 12 KB per workgroup, about what the id's latency covers;
+    //   3. the positions, as soon as the ids are back: they reach the LDS behind 12 KB instead of behind the whole stream, so the
     //      barrier that publishes them falls EARLY in the stream, not at its end;
-    //   4. the nine Dm^-1 planes: every wave computes its F as soon as ITS planes have landed -- wave 0 long before wave 11 --
-    //      so pass 1 runs inside the delivery window instead of behind it;
-    //   5. the neighbour planes (and an explicit operator's weights), which nobody needs before pass 2, go out after the
-    //      barrier: 8 (44 with an operator) of the 52 (88) bytes per slot are off the path to the first F.
-    // (Before: ids, all 13 planes, positions; the positions then arrived last, the barrier fell at ~6.5 k cycles and the whole
-    // of pass 1 -- 4.5 k cycles, every wave at once -- came after the last byte.)
+    //   4. the nine Dm^-1 planes: every wave computes its F as soon as ITS planes have landed;
+    //   5. the neighbour planes (and an explicit operator's weights) and the row table, which nobody needs before pass 2, go
+    //      out after the barrier.
     VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01, q_nb23;
     VF dm[9];
     const int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? a.n_planes : kPlanes);   // (a compile-time constant unless WEIGHTED)
-    // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
-    unsigned char *rs = xs + 16 * VP;
-    const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
-        reinterpret_cast<const GLOBAL_AS unsigned char *>(pl) +
-        ((size_t(kBasePlanes) * td.s_pad * 4 + size_t(td.n_inc4) * 8 + 2 * (size_t(td.n_verts) + 1) + 15) & ~size_t(15)));
+    const GLOBAL_AS uint16_t *g_rowtab = reinterpret_cast<const GLOBAL_AS uint16_t *>(pl + size_t(kBasePlanes) * td.s_pad);
+    // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind the positions
+    const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(g_rowtab + kRowTabEntries);
     v4f rest0 = v4f{0.f, 0.f, 0.f, 0.f};
     if (REBUILD) rest0 = g_rest[tid < td.n_verts ? tid : 0];
     // the positions: unconditional loads (lanes beyond the tile's vertices hold vertex 0 and do not store), so that the
     // stream stays straight-line code whose waits the compiler can count
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(gv0));  // (the wait for the id lands here: vmcnt(2), the two offset planes stay in flight)
+    asm volatile("" : "+v"(gv0));  // (the wait for the id lands here: vmcnt(2), the two vertex planes stay in flight)
     float px, py, pz;
     {
         const size_t gv = size_t(gv0) * 3;
@@ -420,19 +350,17 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
         for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
     }
     __builtin_amdgcn_sched_barrier(0);
-    STAMP(10);   // (stamps builds) everything on the path to the first F is requested
     if (tid < td.n_verts) {
-        reinterpret_cast<float4 *>(xs)[tid] = make_float4(px, py, pz, 0.f);   // (waits for the positions only: vmcnt(9))
-        if (REBUILD) reinterpret_cast<v4f *>(rs)[tid] = rest0;
+        *lds_at<v4f>(kXS + 16u * uint32_t(tid)) = v4f{px, py, pz, 0.f};   // (waits for the positions only: vmcnt(9))
+        if (REBUILD) *lds_at<v4f>(RS + 16u * uint32_t(tid)) = rest0;
     }
     for (int v = tid + nthr; v < td.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
         const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
-        reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        if (REBUILD) reinterpret_cast<v4f *>(rs)[v] = g_rest[v];
+        *lds_at<v4f>(kXS + 16u * uint32_t(v)) = v4f{g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f};
+        if (REBUILD) *lds_at<v4f>(RS + 16u * uint32_t(v)) = g_rest[v];
     }
-    STAMP(11);   // this wave's positions are in the LDS
     __syncthreads();
-    // behind the barrier: what pass 2 needs
+    // behind the barrier: what pass 2 and the end of the tile need
     q_nb01 = plane_u(2), q_nb23 = plane_u(3);
     // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
     // weights for pass 3 replace them after pass 2
@@ -442,56 +370,9 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
     }
+    uint32_t row0 = 0;
+    if (WITH_GRAD && tid < 65) row0 = g_rowtab[tid];   // row table: start of row `tid` of the force array, in 12-byte entries
     __builtin_amdgcn_sched_barrier(0);
-#else
-    // ---- stream the tile: 13 coalesced loads per thread (SPT consecutive slots each, 4 B * SPT per lane) ----
-    VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01 = plane_u(2), q_nb23 = plane_u(3);
-    VF dm[9];
-    const int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? a.n_planes : kPlanes);   // (a compile-time constant unless WEIGHTED)
-    // rest positions of the tile's vertices (rebuild_dminv plans): one coalesced float4 per lane, staged behind xs
-    unsigned char *rs = xs + 16 * VP;
-    const GLOBAL_AS v4f *g_rest = reinterpret_cast<const GLOBAL_AS v4f *>(
-        reinterpret_cast<const GLOBAL_AS unsigned char *>(pl) +
-        ((size_t(kBasePlanes) * td.s_pad * 4 + size_t(td.n_inc4) * 8 + 2 * (size_t(td.n_verts) + 1) + 15) & ~size_t(15)));
-    v4f rest0 = v4f{0.f, 0.f, 0.f, 0.f};
-    if (REBUILD) {
-        rest0 = g_rest[tid < td.n_verts ? tid : 0];
-    } else {
-#pragma unroll
-        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
-    }
-    // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
-    // weights for pass 3 replace them after pass 2
-    VF wd, wk[4];
-    if (WEIGHTED) {
-        wd = plane_f(13);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
-    }
-
-    // stage this tile's vertex positions; the fence keeps the compiler from waiting for the vertex id (and so for
-    // nothing else: vmcnt(13)) before the plane loads above have been issued
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" : "+v"(gv0));  // (address arithmetic on the id would otherwise be hoisted up to its load)
-    if (tid < td.n_verts) {
-        const size_t gv = size_t(gv0) * 3;
-        reinterpret_cast<float4 *>(xs)[tid] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        if (REBUILD) reinterpret_cast<v4f *>(rs)[tid] = rest0;
-    }
-    for (int v = tid + nthr; v < td.n_verts; v += nthr) {  // tiles with more vertices than lanes (rare)
-        const size_t gv = size_t(g_gvid[td.vert_off + v]) * 3;
-        reinterpret_cast<float4 *>(xs)[v] = make_float4(g_x[gv], g_x[gv + 1], g_x[gv + 2], 0.f);
-        if (REBUILD) reinterpret_cast<v4f *>(rs)[v] = g_rest[v];
-    }
-    __syncthreads();
-#endif
-    STAMP(1);
-    if (DBG(DBG_EXIT_AFTER_LOAD)) {
-        float chk = (REBUILD ? rest0.x : dm[0][0] + dm[4][1] + dm[8][SPT - 1]) + float(q_lv01[0] ^ q_lv23[1] ^ q_nb01[0] ^ q_nb23[SPT - 1]) +
-                    reinterpret_cast<float *>(xs)[tid % td.n_verts];
-        if (chk == 12345.678f) g_partials[0] = chk;
-        return;
-    }
 
     // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
     // dE/dF = c1 (Q + (c2 / c1) pen' cof F), so pass 3 works with s_pen = c2 / c1 and the per-vertex sums are scaled
@@ -505,17 +386,19 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     // byte address of each own record's ninth entry (see load_slot), once per slot instead of once per access
     uint32_t t_own_reg[SPT];
 #pragma unroll
-    for (int p = 0; p < SPT; ++p) t_own_reg[p] = own_token_addr(uint32_t(p * nq + tid));
+    for (int p = 0; p < SPT; ++p) t_own_reg[p] = RB + own_token_addr(uint32_t(p * nq + tid));
     // The explicit-operator build has its ten weight registers on top of everything else: there the address is recomputed at
     // each of its five uses (from an opaque copy of the lane id, or the compiler keeps the result in a register all the same)
-    // -- with it the vertex offsets stay in registers for pass 3 like in the built-in kernel, without a spill.
+    // -- with it the vertex fields stay in registers for pass 3 like in the built-in kernel, without a spill.
     auto t_own_at = [&](int p) -> uint32_t {
         if (!WEIGHTED) return t_own_reg[p];
         uint32_t t = uint32_t(tid);
         asm volatile("" : "+v"(t));
-        return own_token_addr(uint32_t(p * nq) + t);
+        return RB + own_token_addr(uint32_t(p * nq) + t);
     };
 #define t_own(p) t_own_at(p)
+    // item number of the lane's p-th slot against the descriptor: owned below n_owned, a real slot below n_slots
+    auto is_owned = [&](int p) { return p * nq + tid < td.n_owned; };
 
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
     float scal[SPT];  // (c2 / c1) * d(penalty)/d(det F), 0 unless owned and inverted
@@ -531,15 +414,15 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
             const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
-            if (REBUILD) rebuild_dminv(rs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p);
+            if (REBUILD) rebuild_dminv(RS, pos_lo(w0), pos_hi(w0), pos_lo(w1), pos_hi(w1), dm, p);
             float F[9];
-            slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
+            slot_F(kXS, pos_lo(w0), pos_hi(w0), pos_lo(w1), pos_hi(w1), dm, p, F);
             if (p < kKeepF) {
 #pragma unroll
                 for (int c = 0; c < 9; ++c) Fk[p][c] = F[c];
             }
-            if (w0 & kOwnedBit) {   // halo slots only contribute F: a real branch (owned / halo is all but wave-uniform in
-                                    // the balanced slot order), tile kernel 0.4643 -> 0.4611 ms (profiles/r03_experiments.md)
+            if (is_owned(p)) {   // halo slots only contribute F: a real branch (owned / halo is all but wave-uniform in
+                                 // the balanced slot order), tile kernel 0.4643 -> 0.4611 ms (profiles/r03_experiments.md)
                 const float J = det3(F);
                 const float Jm = fmaxf(-J, 0.f);
                 float pen = 0.f, dpen = 0.f;
@@ -553,55 +436,36 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 e_b += pen;
                 scal[p] = s_pen * dpen;
             }
-            store_slot(smem, t_own(p), F);
+            store_slot(t_own(p), F);
             SLOT_FENCE();
-#ifdef TSAMD_STAMPS
-            if (p == 0) STAMP(12);   // planes arrived, F of the first slot stored
-#endif
         }
     }
-#ifdef TSAMD_STAMPS
-    STAMP(13);   // this wave's pass 1 done (before the barrier)
-#endif
+    // the row table as LDS byte addresses of the rows (wave 0 and lane 64; read from the scatter phase on)
+    if (WITH_GRAD && tid < 65) *lds_at<uint32_t>(4u * uint32_t(tid)) = RB + 12u * row0;
     __syncthreads();
-#ifdef TSAMD_SLEEP_MID
-    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_MID);
-#endif
-    STAMP(2);  // pass 1 done
-    if (DBG(DBG_EXIT_AFTER_P1)) {
-        if (e_b == 12345.678f) g_partials[0] = e_b;
-        return;
-    }
 
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
-    // With the balanced slot order, position p of lane t is item p * nq + t and items below n_owned
-    // are the owned ones, so `owned` is uniform across all but one wave per position: halo slots
-    // skip their gathers with a real branch.
+    // `owned` is uniform across all but one wave per position: halo slots skip their gathers with a real branch.
     float H[SPT][9];
     auto neighbours = [](uint32_t n01, uint32_t n23, uint32_t *nb) {   // byte addresses of the four records' ninth entries
-        nb[0] = (n01 & kNbMask) << 2;
-        nb[1] = (n01 >> 14) & (kNbMask << 2);
-        nb[2] = (n23 & kNbMask) << 2;
-        nb[3] = (n23 >> 14) & (kNbMask << 2);
+        nb[0] = (n01 & 0xffffu) << 2;
+        nb[1] = (n01 >> 14) & 0x3fffcu;
+        nb[2] = (n23 & 0xffffu) << 2;
+        nb[3] = (n23 >> 14) & 0x3fffcu;
     };
-    if (active && !DBG(DBG_SKIP_P2)) {
+    if (active) {
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
             const uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
-            if (n01 & kOwnedBit) {
+            if (is_owned(p)) {
                 uint32_t nb[4];
                 neighbours(n01, n23, nb);
-                if (DBG(DBG_LOCAL_GATHER2)) nb[0] = nb[1] = nb[2] = nb[3] = t_own(p);
                 Mat9 h;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    h = operator_gather(smem, load_slot(smem, t_own(p)), wd[p], w4, nb);
+                    h = operator_gather(load_slot(t_own(p)), wd[p], w4, nb);
                 } else {
-#ifdef TSAMD_EXP_PARTNER
-                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own(p)), nb, mat9_of(Fk[1 - p]));
-#else
-                    h = laplace_gather(smem, p < kKeepF ? mat9_of(Fk[p]) : load_slot(smem, t_own(p)), nb);
-#endif
+                    h = laplace_gather(p < kKeepF ? mat9_of(Fk[p]) : load_slot(t_own(p)), nb);
                 }
                 v2f sq = h.p01 * h.p01;
                 sq = __builtin_elementwise_fma(h.p23, h.p23, sq);
@@ -616,7 +480,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
                 for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
             }
-            SLOT_FENCE();  // keep one slot's gathers in flight, not four (VGPR budget)
+            SLOT_FENCE();  // keep one slot's gathers in flight, not all of them (VGPR budget)
         }
     } else {
 #pragma unroll
@@ -626,8 +490,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     }
     // ---- the two energy terms are complete: deterministic block reduction (fixed order; doubles across waves) ----
     // Done HERE, around a barrier the tile needs anyway, not at the end of the kernel: there the reduction was a serial
-    // tail (wave sums, a barrier, one lane summing the waves) between this workgroup and its successor on the CU --
-    // 450 cycles per tile even after the DPP rework, and the kernel time follows that tail at better than 1 : 1.
+    // tail (wave sums, a barrier, one lane summing the waves) between this workgroup and its successor on the CU,
+    // and the kernel time follows that tail at better than 1 : 1.
     const int wave = tid / kWave, lane = tid % kWave, nw = (nthr + kWave - 1) / kWave;
     auto publish_wave_sums = [&]() {
         e_s = wave_sum(e_s);
@@ -653,39 +517,28 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
     constexpr bool kSumLate = WITH_GRAD;
     if (!kSumLate) publish_wave_sums();
     __syncthreads();  // every read of F is done; overwrite it with H in place
-    STAMP(3);  // pass 2 done
     if (!kSumLate) sum_waves();
 
     if (WITH_GRAD) {
-        // vertex incidence lists.  The first K2 vertices of the tile get two lanes each (2v and 2v+1 take the even
-        // and the odd chunks), the others one lane (plan.h: vertex_two_lane_count): every vertex is served in one
-        // round.  Each lane fetches its first kPre chunks now so that their HBM latency hides behind pass 3.
-        constexpr int kPre = 3;
-        const GLOBAL_AS v2u *inc = reinterpret_cast<const GLOBAL_AS v2u *>(pl + kBasePlanes * td.s_pad);
-        const GLOBAL_AS uint16_t *inc_off = reinterpret_cast<const GLOBAL_AS uint16_t *>(inc + td.n_inc4);
-        const uint32_t pad16 = (ZS << 2) | 1u;
-        int pc0 = 0, pc1 = 0;
-        v2u pre[kPre];
         if (active) {
             // (Dm^-1, needed again by pass 3, stays in registers)
 #pragma unroll
-            for (int p = 0; p < SPT; ++p) store_slot(smem, t_own(p), H[p]);   // (zeros on halo and padding slots)
+            for (int p = 0; p < SPT; ++p) store_slot(t_own(p), H[p]);   // (zeros on halo and padding slots)
             if (WEIGHTED && a.n_planes == kPlanesWeighted) {   // pass 3 applies L^T: the column weights L[n_k, e] (a symmetric
                                                                // operator has none: the row weights serve both passes)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
             }
         }
-        if (kSumLate) publish_wave_sums();
+        publish_wave_sums();
         __syncthreads();
-        STAMP(4);  // H written, reloads issued
-        if (kSumLate) sum_waves();
+        sum_waves();
 
         // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
-        // Held in registers across the barrier, then written over H (all reads of it done by then).
+        // Held in registers across the barrier, then scattered over H (all reads of it done by then).
         float D[SPT][9];
-        if (active && !DBG(DBG_SKIP_P3)) {
+        if (active) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
                 uint32_t n01 = q_nb01[p], n23 = q_nb23[p];
@@ -694,61 +547,25 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                 asm volatile("" : "+v"(n01), "+v"(n23));
                 uint32_t nb[4];
                 neighbours(n01, n23, nb);
-                if (DBG(DBG_LOCAL_GATHER3)) nb[0] = nb[1] = nb[2] = nb[3] = t_own(p);
-#ifdef TSAMD_DUMMY_LDS   // experiments: marginal cost of LDS reads (conflict-free b128 reads of the own record, results unused)
-                {
-                    v4f dummy;
-#pragma unroll
-                    for (int j = 0; j < TSAMD_DUMMY_LDS; ++j)
-                        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(dummy) : "v"(t_own(p) & ~15u));
-                    asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(dummy));
-                }
-#endif
-                // own H back from LDS (it is 0 on halo slots) rather than 36 VGPRs held across the barrier
                 Mat9 q;
                 if (WEIGHTED) {
                     const float w4[4] = {wk[0][p], wk[1][p], wk[2][p], wk[3][p]};
-                    q = operator_gather(smem, load_slot(smem, t_own(p)), wd[p], w4, nb);
+                    q = operator_gather(load_slot(t_own(p)), wd[p], w4, nb);
                 } else {
-#ifdef TSAMD_EXP_PARTNER
-                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own(p)), nb, mat9_of(H[1 - p]));
-#else
-                    q = laplace_gather(smem, p < kKeepH ? mat9_of(H[p]) : load_slot(smem, t_own(p)), nb);
-#endif
+                    q = laplace_gather(p < kKeepH ? mat9_of(H[p]) : load_slot(t_own(p)), nb);
                 }
-#ifdef TSAMD_DUMMY_VALU  // experiments: marginal cost of VALU instructions (independent FMAs on four accumulators)
-                {
-                    float da[4] = {q.p8, q.p8, q.p8, q.p8};
-#pragma unroll
-                    for (int j = 0; j < TSAMD_DUMMY_VALU; ++j)
-                        asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(da[j & 3]) : "v"(s_pen));
-                    asm volatile("" : : "v"(da[0]), "v"(da[1]), "v"(da[2]), "v"(da[3]));
-                }
-#endif
                 float P[9] = {q.p01.x, q.p01.y, q.p23.x, q.p23.y, q.p45.x, q.p45.y, q.p67.x, q.p67.y, q.p8};
                 if (!factored) {   // rare: c1 == 0 (only the penalty term is left) or c2 / c1 out of range
 #pragma unroll
                     for (int c = 0; c < 9; ++c) P[c] *= q_scale;
                 }
-                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H)
-                    // (the vertex offsets stay in registers from the stream phase on.  Round 2 re-fetched them here from HBM / L2
-                    // "on the rare path" to save four VGPRs -- but the path is rare per TET, not per WAVE: with 1.5 % of the
-                    // headline scene's tets inverted, 63 % of all wave-slots take it, and each paid a global-memory round trip
-                    // in the middle of pass 3.  Keeping them costs one VGPR (78) and no scratch: tile kernel 0.4633 -> 0.4324 ms
-                    // at sigma = 0.02, 0.4793 -> 0.4330 ms at sigma = 0.3; profiles/r03_experiments.md.  The explicit-operator
-                    // build has no register left for them -- it would spill two -- and still re-fetches.)
-#ifdef TSAMD_WEIGHTED_REFETCH
-                    if (WEIGHTED) {   // (the address is rebuilt from an opaque copy of the lane id, or it would be kept in two VGPRs
-                                      // from the stream phase on)
-                        int lt2 = lt;
-                        asm volatile("" : "+v"(lt2));
-                        q_lv01 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 0 * td.s_pad + SPT * lt2);
-                        q_lv23 = *reinterpret_cast<const GLOBAL_AS VU *>(pl + 1 * td.s_pad + SPT * lt2);
-                    }
-#endif
+                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F (it was overwritten by H).  The vertex fields stay in
+                                       // registers from the stream phase on: the path is rare per TET, not per WAVE (with 1.5 % of the
+                                       // headline scene's tets inverted, 63 % of all wave-slots take it), and a re-fetch from memory
+                                       // here cost 7 % of the kernel (profiles/r03_experiments.md)
                     const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
                     float F[9], C[9];
-                    slot_F(xs, w0 & 0x7fffu, w0 >> 16, w1 & 0xffffu, w1 >> 16, dm, p, F);
+                    slot_F(kXS, pos_lo(w0), pos_hi(w0), pos_lo(w1), pos_hi(w1), dm, p, F);
                     cof3(F, C);
 #pragma unroll
                     for (int c = 0; c < 9; ++c) P[c] += scal[p] * C[c];
@@ -760,12 +577,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
                         D[p][3 * k + i] = P[3 * i + 0] * dm[3 * k + 0][p] + P[3 * i + 1] * dm[3 * k + 1][p] +
                                           P[3 * i + 2] * dm[3 * k + 2][p];
                 SLOT_FENCE();
-#ifdef TSAMD_STAMPS
-                if (p == 0) {
-                    asm volatile("" : : "v"(D[0][0]), "v"(D[0][4]), "v"(D[0][8]));
-                    STAMP(14);   // first slot of pass 3 done
-                }
-#endif
             }
         } else {
 #pragma unroll
@@ -773,138 +584,105 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, c
 #pragma unroll
                 for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
         }
-        // (computed here, not earlier: nothing of it needs to stay live across pass 3)
-        const int K2 = vertex_two_lane_count(td.n_verts, nthr);
-        const bool two_lane = tid < 2 * K2;
-        const int my_v = two_lane ? tid >> 1 : K2 + (tid - 2 * K2), my_stride = two_lane ? 2 : 1;
-        const bool has_vertex = my_v < td.n_verts;
-        int32_t dst_row = 0;  // where this lane's vertex goes: fetched here, a whole phase ahead of its use
-        if (has_vertex) {
-            pc0 = inc_off[my_v] + (two_lane ? (tid & 1) : 0);
-            pc1 = inc_off[my_v + 1];
-            dst_row = my_v < td.n_excl ? g_gvid[td.vert_off + my_v] : g_sdst[td.stage_off + (my_v - td.n_excl)];
+        // Where each corner's force goes: row start (LDS byte address, from the table at LDS address 0, indexed by the corner's
+        // rank) + 12 * vertex.  The table is read-only from here on, so its reads are issued ahead of the barrier.
+        uint32_t fdst[SPT][4];
 #pragma unroll
-            for (int q = 0; q < kPre; ++q)
-                pre[q] = pc0 + my_stride * q < pc1 ? inc[pc0 + my_stride * q] : v2u{pad16 * 0x10001u, pad16 * 0x10001u};
+        for (int p = 0; p < SPT; ++p) {
+            const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];
+            const uint32_t r0 = *lds_at<const uint32_t>((w0 >> 8) & 0xfcu), r1 = *lds_at<const uint32_t>((w0 >> 24) & 0xfcu),
+                           r2 = *lds_at<const uint32_t>((w1 >> 8) & 0xfcu), r3 = *lds_at<const uint32_t>((w1 >> 24) & 0xfcu);
+            fdst[p][0] = (w0 & kVertMask) * 12u + r0;
+            fdst[p][1] = ((w0 >> 16) & kVertMask) * 12u + r1;
+            fdst[p][2] = (w1 & kVertMask) * 12u + r2;
+            fdst[p][3] = ((w1 >> 16) & kVertMask) * 12u + r3;
         }
-        STAMP(5);  // pass 3 compute done (this wave)
-        __syncthreads();
-        STAMP(6);  // all waves done with H and with the staged positions
-        // ---- write the vertex forces: record = (f0.xyz, f1.xyz, f2.xyz, f3.xyz), f0 = -(f1 + f2 + f3) ----
+        // the vertex blocks of this wave in the per-vertex sum: 64 consecutive tile vertices each; waves 4-7 take their four
+        // blocks in reverse so that every SIMD (waves w, w + 4, w + 8) gets one long and one short block of the sorted vertices
+        const int vb0 = (wave & 4) ? (wave ^ 3) : wave;
+        int32_t dst_row = 0;  // where this lane's first vertex goes: fetched here, a whole phase ahead of its use
+        if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];
+        __syncthreads();   // all waves done with H and with the staged positions
+        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----
         if (active) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
-                const uint32_t r = t_own(p) & ~15u;
-                const float *d = D[p];
-                *lds_at<v4f>(r) = v4f{-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8]), d[0]};
-                *lds_at<v4f>(r + 16) = v4f{d[1], d[2], d[3], d[4]};
-                *lds_at<v4f>(r + 32) = v4f{d[5], d[6], d[7], d[8]};
+                if (p * nq + tid < td.n_slots) {   // (padding slots -- at most three, the last lanes -- have no entries)
+                    const float *d = D[p];
+                    LDS_AS float *f0 = lds_at<float>(fdst[p][0]), *f1 = lds_at<float>(fdst[p][1]), *f2 = lds_at<float>(fdst[p][2]),
+                                 *f3 = lds_at<float>(fdst[p][3]);
+                    f0[0] = -(d[0] + d[3] + d[6]), f0[1] = -(d[1] + d[4] + d[7]), f0[2] = -(d[2] + d[5] + d[8]);
+                    f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];
+                    f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];
+                    f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];
+                }
             }
         }
-        if (tid < 12) lds_at<float>(ZS * 48u)[tid] = 0.f;  // the all-zero record the list padding points at
         __syncthreads();
-        STAMP(7);  // vertex forces written
 
-        // ---- per-vertex gather of the incident tets' forces: fixed order, no atomics ----
-        // Entry e = (lds record << 2) | local vertex; its 3 floats sit at byte 12 e.  Padding entries
-        // point into the all-zero slot.  Exclusive vertices go straight to grad, vertices shared with
-        // other tiles to the staging rows, which the finish kernel sums in plan order.
-        // The plan sorts a tile's vertices by list length, so the lanes of one wave need about the same
-        // number of chunks and a wave stops at its own longest list.
+        // ---- per-vertex sums: lane = vertex, rows in order (= slot order: fixed, no atomics) ----
+        // Lane r of every wave holds row r's start address and width: the row loop is wave-uniform (v_readlane), its trip
+        // count the slot count of the wave's first -- fullest -- vertex.  Exclusive vertices go straight to grad, vertices
+        // shared with other tiles to the staging rows, which the finish kernel sums in plan order.
         const float gscale = (a.grad_out ? *as_global(a.grad_out) : 1.f) * out_scale;
-        for (int v = my_v, round = 0; v < td.n_verts; v += nthr, ++round) {   // (a second round only if n_verts > nthr)
+        const uint32_t tab = *lds_at<const uint32_t>(4u * uint32_t(lane));
+        const uint32_t wid = *lds_at<const uint32_t>(4u * uint32_t(lane) + 4u) - tab;   // 12 * (vertices in row `lane`)
+        for (int vb = vb0; 64 * vb < td.n_verts; vb += nw) {
+            const int v = 64 * vb + lane;
+            const uint32_t v12 = 12u * uint32_t(v);
+            const int rows = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wid > 768u * uint32_t(vb)));
             float gx = 0.f, gy = 0.f, gz = 0.f;
-            auto gather4 = [&](const v2u w) {
-                const uint32_t ent[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+            // (four rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
+            // beyond the tile's last one are empty: width 0)
+            for (int r = 0; r < rows; r += 4) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const LDS_AS float *f = lds_at<const float>(ent[q] * 12u);
-                    gx += f[0];
-                    gy += f[1];
-                    gz += f[2];
-                }
-            };
-            int32_t row = dst_row;
-            if (!DBG(DBG_SKIP_VGATHER)) {
-                int c, c1;
-                if (round == 0) {  // prefetched chunks; a wave skips the steps none of its lanes needs
-                    c = pc0;
-                    c1 = pc1;
-#pragma unroll
-                    for (int q = 0; q < kPre; ++q) {
-                        if (__builtin_amdgcn_ballot_w64(c < c1) == 0) break;
-                        gather4(pre[q]);
-                        c += my_stride;
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
+                    if (v12 < w) {
+                        const LDS_AS float *f = lds_at<const float>(base + v12);
+                        gx += f[0];
+                        gy += f[1];
+                        gz += f[2];
                     }
-                } else {
-                    c = inc_off[v];
-                    c1 = inc_off[v + 1];
-                    row = v < td.n_excl ? g_gvid[td.vert_off + v] : g_sdst[td.stage_off + (v - td.n_excl)];
                 }
-                for (; c < c1; c += my_stride) gather4(inc[c]);
             }
-            if (two_lane) {
-                // even lane + odd lane (quad_perm [1,0,3,2]); both lanes end up with the same sum
-                gx += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gx), 0xB1, 0xf, 0xf, false));
-                gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xf, 0xf, false));
-                gz += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gz), 0xB1, 0xf, 0xf, false));
-                if (tid & 1) continue;
+            if (v < td.n_verts) {
+                const int32_t row = vb == vb0 ? dst_row : g_vdst[td.vert_off + v];
+                const bool excl = row >= 0;
+                GLOBAL_AS float *dst = (excl ? g_grad : g_stage) + size_t(excl ? row : ~row) * 3;
+                const float sc = excl ? gscale : out_scale;
+                // (non-temporal stores here were measured: tile kernel +28 %; the wave's end waits for their acknowledgement)
+                dst[0] = gx * sc;
+                dst[1] = gy * sc;
+                dst[2] = gz * sc;
             }
-            GLOBAL_AS float *dst = (v < td.n_excl ? g_grad : g_stage) + size_t(row) * 3;
-            if (DBG(DBG_STORE_LOCAL)) dst = g_stage + size_t(tid) * 3;   // same store instructions, no HBM writes, no scatter
-            const float sc = v < td.n_excl ? gscale : out_scale;
-            if (DBG(DBG_SKIP_OUT)) {
-                if (gx == 1234.5f) dst[0] = gy + gz;
-                continue;
-            }
-            // (non-temporal stores here were measured: tile kernel +28 %; the wave's end waits for their acknowledgement)
-            dst[0] = gx * sc;
-            dst[1] = gy * sc;
-            dst[2] = gz * sc;
         }
     }
-
-#ifdef TSAMD_SLEEP_END
-    __builtin_amdgcn_s_sleep(TSAMD_SLEEP_END);
-#endif
-    STAMP(8);  // vertex gather + stores done (this wave): nothing is left to do, the wave ends here
-#ifdef TSAMD_ABLATION
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamp 9 - stamp 8 = what s_endpgm waits for: the result stores' acknowledgement
-#endif
-    STAMP(9);
 #undef t_own
 }
 
-
-
-template <bool WITH_GRAD, int BLOCK, int WPE, bool WEIGHTED = false, bool REBUILD = false>
+template <bool WITH_GRAD, int BLOCK, int WPE, bool WEIGHTED = false, bool REBUILD = false, int SPT = kSlotsPerLane>
 __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
     // XCD-aware tile order: workgroup b lands on XCD b % 8 (observed, speed only), so give each
-    // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2 and the halo
-    // planes two neighbouring tiles both read are served from it.
+    // XCD a contiguous run of tiles -- the tiles of one sphere then share one L2.
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
     const int tile = xcd * a.tiles_per_xcd + jb;
     if (jb >= a.tiles_per_xcd || tile >= tile_end) return;
     // (lds_at() assumes the dynamic LDS array starts at LDS address 0: true for a kernel without static LDS objects,
-    // which configure_kernels() verifies on the host.  A run-time check here costs more than it looks: a trap in the
-    // prologue turns the descriptor loads into vector loads and their 12 dwords, and every address derived from them,
-    // into VGPRs -- measured +26 VGPRs.)
+    // which configure_kernels() verifies on the host.)
     // The position gather is the longest dependent chain at the head of a tile: vertex id -> position -> LDS.  The id's
     // address needs only the tile number and a kernel argument (vertex ids sit at tile * vert_stride, plan.cpp), so it is
     // requested HERE, before the tile descriptor is even asked for: the chain is two memory latencies instead of three.
     // Entries beyond n_verts name vertex 0 and are never used.
     const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];
     __builtin_amdgcn_sched_barrier(0);
-    const TileDesc td0 = a.tiles[tile];
-    tile_body<WITH_GRAD, WEIGHTED, REBUILD>(a, tile, td0.s_pad + 4, (td0.n_verts + 3) & ~3, gv0);
+    tile_body<WITH_GRAD, WEIGHTED, REBUILD, SPT>(a, tile, gv0);
 }
 
 struct FinishArgs {
-    const int32_t *fin_vid, *fin_off, *fin_idx;
+    const int32_t *fin_vid, *fin_off;
     int64_t n_finish;
     const float *stage;
     float *grad;
@@ -1164,46 +942,57 @@ int grid_for(int64_t n, int per_block, int cap)
 
 hipError_t launch_eval_kernels(const EvalArgs &e, hipStream_t stream, hipEvent_t *ev);
 
-#ifdef TSAMD_ABLATION
-// experiments only: request more dynamic LDS than the tiles need, to limit the workgroups per CU (tools/ablate.py)
-static size_t ablation_lds_request(size_t lds)
+namespace {
+
+// The lane layouts tile kernels are built for: (slots per lane, block-size cap, waves per SIMD of the launch bounds).
+//   2 x 768 @ 6 : 80 VGPRs, two workgroups of <= 80 KiB per CU -- the default, every operator variant
+//   3 x 512 @ 4 : 128 VGPRs, two workgroups per CU of fewer, fatter waves (built-in operator)
+//   4 x 768 @ 3 : 168 VGPRs, one workgroup per CU with up to 160 KiB: whole small tet-spheres as ONE tile, no halo, no
+//   3 x 1024 @ 4: 128 VGPRs, the same with more waves                   shared vertices (built-in operator)
+#define TSAMD_FN(...) reinterpret_cast<const void *>(&tile_energy_kernel<__VA_ARGS__>)
+const void *tile_kernel_for(int spt, int block_threads, bool grad, bool weighted, bool rebuild)
 {
-    static const char *s = getenv("TSAMD_LDS_REQUEST");
-    const size_t v = s ? size_t(strtoul(s, nullptr, 10)) : 0;
-    return v > lds ? v : lds;
+    if (spt == 2 && block_threads <= 768) {
+        if (weighted) return grad ? TSAMD_FN(true, 768, 6, true, false, 2) : TSAMD_FN(false, 768, 6, true, false, 2);
+        if (rebuild) return grad ? TSAMD_FN(true, 768, 6, false, true, 2) : TSAMD_FN(false, 768, 6, false, true, 2);
+        return grad ? TSAMD_FN(true, 768, 6, false, false, 2) : TSAMD_FN(false, 768, 6, false, false, 2);
+    }
+    if (weighted || rebuild) return nullptr;
+    if (spt == 3 && block_threads <= 512) return grad ? TSAMD_FN(true, 512, 4, false, false, 3) : TSAMD_FN(false, 512, 4, false, false, 3);
+    if (spt == 4 && block_threads <= 768) return grad ? TSAMD_FN(true, 768, 3, false, false, 4) : TSAMD_FN(false, 768, 3, false, false, 4);
+    if (spt == 3 && block_threads <= 1024) return grad ? TSAMD_FN(true, 1024, 4, false, false, 3) : TSAMD_FN(false, 1024, 4, false, false, 3);
+    return nullptr;
 }
-#endif
+#undef TSAMD_FN
+
+}  // namespace
+
+bool lane_layout_supported(int spt, int max_threads) { return tile_kernel_for(spt, max_threads, true, false, false) != nullptr; }
 
 hipError_t configure_kernels(int lds_bytes)
 {
-#ifdef TSAMD_ABLATION
-    lds_bytes = int(ablation_lds_request(size_t(lds_bytes)));
-#endif
     // hipFuncAttributeMaxDynamicSharedMemorySize is per function, i.e. per process and device -- not per handle: only
     // ever raise it, or a handle with small tiles would lower the limit under an earlier handle with large ones
     static int configured[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (lds_bytes <= configured[dev]) return hipSuccess;
-    // every tile kernel a plan can reach: the built-in operator, an explicit operator, rebuild_dminv -- each with and
-    // without the gradient
-    const void *fns[] = {reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<true, kTileThreads, 6, false, true>),
-                         reinterpret_cast<const void *>(&tile_energy_kernel<false, kTileThreads, 6, false, true>)};
-    for (const void *fn : fns) {
-        // lds_at() addresses the dynamic LDS array by absolute byte address: that is only right while the array starts
-        // at LDS address 0, i.e. while the kernel has no static LDS object in front of it (a static __shared__ variable,
-        // an LDS-using helper that was not inlined, a compiler-generated module-LDS block)
-        hipFuncAttributes attr;
-        hipError_t e = hipFuncGetAttributes(&attr, fn);
-        if (e != hipSuccess) return e;
-        if (attr.sharedSizeBytes != 0) return hipErrorInvalidDeviceFunction;
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (e != hipSuccess) return e;
-    }
+    // every tile kernel a plan can reach
+    static const int layouts[][2] = {{2, 768}, {3, 512}, {4, 768}, {3, 1024}};
+    for (const auto &lay : layouts)
+        for (int variant = 0; variant < 6; ++variant) {
+            const void *fn = tile_kernel_for(lay[0], lay[1], (variant & 1) != 0, variant / 2 == 1, variant / 2 == 2);
+            if (!fn) continue;
+            // lds_at() addresses the dynamic LDS array by absolute byte address: that is only right while the array starts
+            // at LDS address 0, i.e. while the kernel has no static LDS object in front of it (a static __shared__ variable,
+            // an LDS-using helper that was not inlined, a compiler-generated module-LDS block)
+            hipFuncAttributes attr;
+            hipError_t e = hipFuncGetAttributes(&attr, fn);
+            if (e != hipSuccess) return e;
+            if (attr.sharedSizeBytes != 0) return hipErrorInvalidDeviceFunction;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            if (e != hipSuccess) return e;
+        }
     configured[dev] = lds_bytes;
     return hipSuccess;
 }
@@ -1239,7 +1028,7 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
         k.tiles = e.tiles;
         k.blob = e.blob;
         k.gvid = e.gvid;
-        k.sdst = e.fin_idx;
+        k.vdst = e.vdst;
         k.x = e.x;
         k.grad_out = e.grad_out;
         k.grad = e.grad;
@@ -1253,29 +1042,15 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
         k.tiles_per_xcd = int((e.n_tiles + 7) / 8);
         k.vert_stride = e.vert_stride;
         k.n_planes = e.n_planes;
-        k.dbg = e.dbg;
-        k.clk = e.clk;
-        if (e.block_threads > kTileThreads) return hipErrorInvalidConfiguration;
+        r.tile_fn = tile_kernel_for(e.spt, e.block_threads, e.grad != nullptr, e.weighted, e.rebuild);
+        if (!r.tile_fn) return hipErrorInvalidConfiguration;
         r.tile_block = dim3(unsigned(e.block_threads));
         r.tile_grid = dim3(unsigned(8 * k.tiles_per_xcd));
-#ifdef TSAMD_ABLATION
-        r.tile_lds = ablation_lds_request(size_t(e.lds_bytes));
-#else
         r.tile_lds = size_t(e.lds_bytes);
-#endif
-#define TSAMD_FN(...) reinterpret_cast<const void *>(&tile_energy_kernel<__VA_ARGS__>)
-        if (e.weighted)
-            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6, true) : TSAMD_FN(false, kTileThreads, 6, true);
-        else if (e.rebuild)
-            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6, false, true) : TSAMD_FN(false, kTileThreads, 6, false, true);
-        else
-            r.tile_fn = e.grad ? TSAMD_FN(true, kTileThreads, 6) : TSAMD_FN(false, kTileThreads, 6);
-#undef TSAMD_FN
     }
     FinishArgs &f = r.f;
     f.fin_vid = e.fin_vid;
     f.fin_off = e.fin_off;
-    f.fin_idx = e.fin_idx;
     f.n_finish = e.grad ? e.n_finish : 0;
     f.stage = e.stage;
     f.grad = e.grad;
@@ -1538,37 +1313,6 @@ void train_loop_destroy(TrainLoopGraph *g)
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
     delete g;
-}
-
-// The finish launch on its own (shared-vertex sums in plan order + energy reduction), for the streaming-tile path.
-hipError_t launch_finish(const int32_t *fin_vid, const int32_t *fin_off, int64_t n_finish, const float *stage, float *grad,
-                         const float *grad_out, const double *partials, int64_t n_partials, float c1, float c2, float *energy,
-                         double *terms, hipStream_t stream)
-{
-    FinishArgs f;
-    f.fin_vid = fin_vid;
-    f.fin_off = fin_off;
-    f.fin_idx = nullptr;
-    f.n_finish = n_finish;
-    f.stage = stage;
-    f.grad = grad;
-    f.grad_out = grad_out;
-    f.partials = partials;
-    f.n_tiles = n_partials;
-    f.c1 = c1;
-    f.c2 = c2;
-    f.coef = nullptr;
-    f.energy = energy;
-    f.terms = terms;
-    if (n_finish > 0) {
-        hipLaunchKernelGGL(finish_kernel, dim3(1u + unsigned(grid_for(n_finish, 256, 1 << 20))), dim3(256), 0, stream, f);
-        return hipGetLastError();
-    }
-    if (energy) {
-        hipLaunchKernelGGL(energy_reduce_kernel, dim3(1), dim3(1024), 0, stream, f);
-        return hipGetLastError();
-    }
-    return hipSuccess;
 }
 
 hipError_t launch_scale(const float *in, const float *scalar, float *out, int64_t n, hipStream_t stream)

@@ -179,10 +179,11 @@ struct Scratch {
 struct Limits {
     int64_t budget;
     int64_t max_spad;
+    int64_t pad_unit = 4;
     bool rebuild = false;
     bool fits(int64_t n_slots, int64_t n_verts) const
     {
-        const int64_t sp = (n_slots + 3) & ~int64_t(3);
+        const int64_t sp = (n_slots + pad_unit - 1) / pad_unit * pad_unit;
         return sp <= max_spad && n_verts <= kMaxTileVerts && tile_lds_bytes(sp, n_verts, rebuild) <= budget;
     }
 };
@@ -194,7 +195,8 @@ struct Mesh {
     int64_t n, m;
 };
 
-// owned + one-ring halo size and the number of distinct vertices they touch
+// owned + one-ring halo size and the number of tile vertices they touch (a vertex met by more than kMaxRank slots of
+// the tile is split into several tile vertices of at most kMaxRank slots each, see build_plan)
 void measure(const Mesh &M, const int32_t *owned, int64_t cnt, Scratch &S, int64_t &n_slots, int64_t &n_verts,
              std::vector<int32_t> *halo_out = nullptr)
 {
@@ -207,6 +209,9 @@ void measure(const Mesh &M, const int32_t *owned, int64_t cnt, Scratch &S, int64
             int32_t v = M.tets[4 * int64_t(e) + a];
             if (S.vert_stamp[v] != so) {
                 S.vert_stamp[v] = so;
+                S.vert_local[v] = 1;
+                ++verts;
+            } else if (S.vert_local[v]++ % kMaxRank == 0) {
                 ++verts;
             }
         }
@@ -348,20 +353,26 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     // colouring, incidence matching: 1.0-1.1 s) does not get faster.  An explicit num_threads is honoured up to 64.
     int nthreads = opt.num_threads > 0 ? std::min(opt.num_threads, 64) : std::min(int(std::thread::hardware_concurrency()), 32);
     nthreads = std::max(1, nthreads);
-    constexpr int spt = kSlotsPerLane;
+    const int spt = opt.slots_per_lane > 0 ? opt.slots_per_lane : kSlotsPerLane;
+    if (spt < 2 || spt > 4) {
+        err = "slots_per_lane must be 2, 3 or 4";
+        return ERR_INVALID;
+    }
     // Defaults: 768 threads x 2 slots and 80 KiB, two workgroups per CU -- with or without an explicit operator (its nine
-    // extra planes live in registers, not in LDS, and the kernel still fits 80 VGPRs).
-    if (opt.max_threads > kTileThreads) {
-        err = "max_threads exceeds what the tile kernels are compiled for (" + std::to_string(kTileThreads) + ")";
+    // extra planes live in registers, not in LDS, and the kernel still fits 80 VGPRs).  (Which block sizes go with which
+    // lane layout is the launcher's business: capi.cpp.)
+    if (opt.max_threads > 1024) {
+        err = "max_threads exceeds 1024";
         return ERR_INVALID;
     }
     int max_threads = opt.max_threads > 0 ? opt.max_threads : kTileThreads;
     max_threads = std::max(64, (max_threads / 64) * 64);
     Limits lim;
     lim.budget = opt.lds_budget > 0 ? opt.lds_budget : 80 * 1024;
-    lim.max_spad = std::min<int64_t>(int64_t(spt) * int64_t(max_threads), 2728);  // record tokens (12 idx + rot) are 15-bit fields
+    lim.pad_unit = spt == 3 ? 12 : 4;
+    lim.max_spad = int64_t(spt) * int64_t(max_threads) / lim.pad_unit * lim.pad_unit;
     lim.rebuild = opt.rebuild_dminv != 0 && op == nullptr;
-    if (lim.budget < tile_lds_bytes(8, 8, lim.rebuild)) {
+    if (lim.budget < tile_lds_bytes(12, 8, lim.rebuild)) {
         err = "lds_budget_bytes too small";
         return ERR_INVALID;
     }
@@ -570,7 +581,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         }
     }
     // LDS: 48 B per slot + 16 B per vertex at ~0.27 vertices per slot
-    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - 256 - 192) / (rebuild ? 58 : 53));
+    int64_t s_cap = std::min<int64_t>(lim.max_spad, (lim.budget - kRowTabBytes - 256) / (rebuild ? 58 : 53));
     int64_t target = opt.target_owned > 0 ? opt.target_owned : int64_t(0.70 * double(s_cap));
     target = std::max<int64_t>(1, target);
 
@@ -627,71 +638,65 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     group_tiles.clear();
     const int64_t T = int64_t(tiles_owned.size());
 
-    // ---- pass A: per-tile halo + vertex lists, global per-vertex tile count ----
-    std::vector<std::vector<int32_t>> tile_halo(static_cast<size_t>(T)), tile_verts(static_cast<size_t>(T));
-    std::vector<int32_t> tile_inc4(static_cast<size_t>(T), 0);
-    std::vector<std::vector<int32_t>> tile_vcnt(static_cast<size_t>(T));  // incidence entries per tile vertex
+    // ---- pass A: per-tile halo + vertex lists, global per-vertex copy count ----
+    // A tile vertex is (global vertex, copy): a vertex met by more than kMaxRank slots of the tile (a hub: the cone fixture's
+    // centre meets ~1 500 slots of every tile) is split into copies of at most kMaxRank slots each, so that a slot's rank at a
+    // corner fits the six spare bits of its vertex field; the copies are staged from the same position, their partial sums
+    // go through the staging rows like any vertex shared by several tiles, and the finish kernel adds them up.
+    // Tile vertices are numbered by FALLING slot count: row r of the tile's force array (plan.h) is then the prefix of the
+    // vertices met by more than r slots, and the lanes of one wave of the per-vertex sum carry about the same number of rows.
+    std::vector<std::vector<int32_t>> tile_halo(static_cast<size_t>(T)), tile_verts(static_cast<size_t>(T)), tile_vdeg(static_cast<size_t>(T));
     std::vector<std::atomic<int32_t>> vcount(static_cast<size_t>(n));
     for (auto &a : vcount) a.store(0, std::memory_order_relaxed);
     parallel_chunks(T, 4, nthreads, [&](int64_t b, int64_t e, int w) {
         Scratch &S = get_scratch(w);
+        std::vector<int32_t> uniq, cnt;
+        std::vector<std::pair<int32_t, int32_t>> key;   // (-slots, global vertex), in first-touch order before the sort
         for (int64_t t = b; t < e; ++t) {
             const auto &own = tiles_owned[size_t(t)];
             int64_t ns, nv;
             measure(M, own.data(), int64_t(own.size()), S, ns, nv, &tile_halo[size_t(t)]);
-            auto &tv = tile_verts[size_t(t)];
-            tv.reserve(size_t(nv));
+            uniq.clear();
+            cnt.clear();
             const int32_t st = S.next();
             auto touch = [&](int32_t el) {
                 for (int a = 0; a < 4; ++a) {
-                    int32_t v = tets[4 * int64_t(el) + a];
+                    const int32_t v = tets[4 * int64_t(el) + a];
                     if (S.vert_stamp[v] != st) {
                         S.vert_stamp[v] = st;
-                        tv.push_back(v);
+                        S.vert_local[v] = int32_t(uniq.size());
+                        uniq.push_back(v);
+                        cnt.push_back(0);
                     }
+                    ++cnt[size_t(S.vert_local[v])];
                 }
             };
             for (int32_t el : own) touch(el);
             for (int32_t el : tile_halo[size_t(t)]) touch(el);
-            for (int32_t v : tv) vcount[size_t(v)].fetch_add(1, std::memory_order_relaxed);
-            // incidence chunks: every vertex's (slot, a) list is padded to a multiple of 4 entries
-            {
-                auto &cnt = tile_vcnt[size_t(t)];
-                cnt.assign(tv.size(), 0);
-                for (size_t i = 0; i < tv.size(); ++i) S.vert_local[tv[i]] = int32_t(i);
-                auto count = [&](int32_t el) {
-                    for (int a = 0; a < 4; ++a) ++cnt[size_t(S.vert_local[tets[4 * int64_t(el) + a]])];
-                };
-                for (int32_t el : own) count(el);
-                for (int32_t el : tile_halo[size_t(t)]) count(el);
-                int64_t chunks = 0;
-                for (int32_t c : cnt) chunks += (c + 3) / 4;
-                tile_inc4[size_t(t)] = int32_t(chunks);
-            }
-        }
-    });
-
-    timer.lap("pass A (halo, vertex lists)");
-    // ---- tile vertex order: exclusive vertices first, then the shared ones; inside each class longest
-    // incidence list first, so that the lanes of a wave of the per-vertex gather carry lists of about the
-    // same length (a wave runs as long as its longest list) ----
-    parallel_chunks(T, 8, nthreads, [&](int64_t b, int64_t e, int) {
-        std::vector<std::pair<int32_t, int32_t>> key;
-        for (int64_t t = b; t < e; ++t) {
-            auto &tv = tile_verts[size_t(t)];
-            auto &cnt = tile_vcnt[size_t(t)];
-            key.resize(tv.size());
-            for (size_t i = 0; i < tv.size(); ++i) {
-                const bool shared = vcount[size_t(tv[i])].load(std::memory_order_relaxed) != 1;
-                key[i] = {(shared ? 1 << 20 : 0) - (cnt[i] + 3) / 4, tv[i]};
+            key.clear();
+            for (size_t i = 0; i < uniq.size(); ++i) {
+                int32_t left = cnt[i], copies = 0;
+                while (left > 0) {
+                    const int32_t c = std::min<int32_t>(left, kMaxRank);
+                    key.push_back({-c, uniq[i]});
+                    left -= c;
+                    ++copies;
+                }
+                vcount[size_t(uniq[i])].fetch_add(copies, std::memory_order_relaxed);
             }
             std::stable_sort(key.begin(), key.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-            for (size_t i = 0; i < tv.size(); ++i) tv[i] = key[i].second;
-            std::vector<int32_t>().swap(cnt);
+            auto &tv = tile_verts[size_t(t)];
+            auto &td = tile_vdeg[size_t(t)];
+            tv.resize(key.size());
+            td.resize(key.size());
+            for (size_t i = 0; i < key.size(); ++i) {
+                tv[i] = key[i].second;
+                td[i] = -key[i].first;
+            }
         }
     });
 
-    timer.lap("vertex order");
+    timer.lap("pass A (halo, vertex lists, vertex order)");
     // ---- offsets ----
     P.tiles.resize(size_t(T));
     P.slot_base.resize(size_t(T) + 1);
@@ -711,20 +716,19 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
         for (int32_t v : tv) n_excl += vcount[size_t(v)].load(std::memory_order_relaxed) == 1;
         d.n_owned = int32_t(tiles_owned[size_t(t)].size());
         d.n_slots = d.n_owned + int32_t(tile_halo[size_t(t)].size());
-        d.s_pad = (d.n_slots + 3) & ~3;
+        d.s_pad = int32_t((d.n_slots + lim.pad_unit - 1) / lim.pad_unit * lim.pad_unit);
         d.n_verts = int32_t(tv.size());
         d.n_excl = n_excl;
         d.blob_off = uint64_t(blob_bytes);
         d.vert_off = int32_t(vert_off);
         d.stage_off = stage_off;
-        d.n_inc4 = tile_inc4[size_t(t)];
-        if (d.n_inc4 > 65535) {
-            err = "tile incidence list too long for 16-bit chunk offsets";
+        d.n_rows = tv.empty() ? 0 : tile_vdeg[size_t(t)][0];
+        d.rec_base = int32_t(tile_rec_base(d.n_verts, rebuild));
+        if (d.n_verts > kMaxTileVerts || 4 * int64_t(d.s_pad) > 65535) {
+            err = "tile exceeds the 10-bit vertex / 16-bit entry fields of the plan";
             return ERR_TILING;
         }
-        blob_bytes += ((rebuild ? tile_rest_offset(n_planes, d.s_pad, d.n_inc4, d.n_verts) + 16 * int64_t(d.n_verts)
-                                : int64_t(n_planes) * d.s_pad * 4 + int64_t(d.n_inc4) * 8 + 2 * (int64_t(d.n_verts) + 1)) + 127) &
-                      ~int64_t(127);
+        blob_bytes += (tile_rest_offset(n_planes, d.s_pad) + (rebuild ? 16 * int64_t(d.n_verts) : 0) + 127) & ~int64_t(127);
         vert_off += vert_stride;
         P.total_tile_verts += d.n_verts;
         stage_off += d.n_verts - d.n_excl;
@@ -745,38 +749,77 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     P.block_threads = std::min(max_threads, ((max_quads + 63) / 64) * 64);
     P.blob.resize(size_t(blob_bytes / 4));   // (uninitialised: every tile zero-fills its own range in pass B)
     P.gvid.resize(size_t(vert_off));
+    P.vdst.resize(size_t(vert_off));
     P.slot_tet.resize(size_t(slot_off));
 
-    timer.lap("offsets + allocation");
+    // ---- finish lists: every vertex with more than one tile-vertex copy; staging rows vertex-major, copies in tile order ----
+    // (tile-major rows + a gather in the finish kernel was measured: tile kernel unchanged, finish kernel 0.046 -> 0.084 ms)
+    std::vector<int32_t> fin_of(static_cast<size_t>(n), -1);
+    {
+        int64_t entries = 0;
+        for (int64_t v = 0; v < n; ++v) {
+            int32_t c = vcount[size_t(v)].load(std::memory_order_relaxed);
+            if (c == 1) continue;
+            fin_of[size_t(v)] = int32_t(P.fin_vid.size());
+            P.fin_vid.push_back(int32_t(v));
+            P.fin_off.push_back(int32_t(entries));
+            entries += c;
+            if (entries >= (int64_t(1) << 31)) {
+                err = "too many shared vertex copies for 32-bit offsets";
+                return ERR_TILING;
+            }
+        }
+        P.fin_off.push_back(int32_t(entries));
+        P.fin_idx.assign(size_t(entries), 0);
+        std::vector<int32_t> cur(P.fin_off.begin(), P.fin_off.end() - 1);
+        for (int64_t t = 0; t < T; ++t) {
+            const TileDesc &d = P.tiles[size_t(t)];
+            const auto &tv = tile_verts[size_t(t)];
+            int64_t j = 0;
+            int32_t *vd = P.vdst.data() + d.vert_off;
+            for (int32_t i = 0; i < d.n_verts; ++i) {
+                const int32_t v = tv[size_t(i)];
+                const int32_t k = fin_of[size_t(v)];
+                if (k < 0) {
+                    vd[i] = v;
+                } else {
+                    const int32_t row = cur[size_t(k)]++;
+                    vd[i] = ~row;
+                    P.fin_idx[size_t(d.stage_off + j++)] = row;
+                }
+            }
+            std::fill_n(vd + d.n_verts, size_t(P.vert_stride - d.n_verts), int32_t(0));
+        }
+    }
+    timer.lap("offsets + allocation + finish lists");
     // ---- pass B: fill planes ----
     std::atomic<int> singular{0};
-    const bool balance = opt.balance != 0;
     parallel_chunks(T, 2, nthreads, [&](int64_t b, int64_t e, int w) {
         Scratch &S = get_scratch(w);
+        std::vector<int32_t> next_rank, copy_of;      // per tile vertex: ranks handed out so far; next copy of the same vertex (-1: none)
         for (int64_t t = b; t < e; ++t) {
             const TileDesc &d = P.tiles[size_t(t)];
             const auto &own = tiles_owned[size_t(t)];
             const auto &halo = tile_halo[size_t(t)];
             const auto &tv = tile_verts[size_t(t)];
+            const auto &tdeg = tile_vdeg[size_t(t)];
             const int32_t st = S.next();
-            for (int32_t i = 0; i < d.n_verts; ++i) {
-                S.vert_stamp[tv[size_t(i)]] = st;
-                S.vert_local[tv[size_t(i)]] = i;
-                P.gvid[size_t(d.vert_off) + size_t(i)] = tv[size_t(i)];
+            // global vertex -> its first copy (the copies of a hub follow each other through copy_of, fullest first)
+            copy_of.assign(size_t(d.n_verts), -1);
+            next_rank.assign(size_t(d.n_verts), 0);
+            for (int32_t i = d.n_verts - 1; i >= 0; --i) {
+                const int32_t v = tv[size_t(i)];
+                if (S.vert_stamp[v] == st) copy_of[size_t(i)] = S.vert_local[v];
+                S.vert_stamp[v] = st;
+                S.vert_local[v] = i;
+                P.gvid[size_t(d.vert_off) + size_t(i)] = v;
             }
             std::fill_n(P.gvid.data() + d.vert_off + d.n_verts, size_t(P.vert_stride - d.n_verts), int32_t(0));   // unused entries: vertex 0
             const int32_t nq = d.s_pad / spt;
-            // shuffle: item L -> item (L * stride) mod n_slots with an odd-ish stride coprime to n_slots, so
-            // that the lanes of one wave hold tets that are far apart (no shared vertices)
-            int64_t stride = 1;
-            if (opt.shuffle && d.n_slots > 2) {
-                stride = std::max<int64_t>(2, int64_t(0.6180339887 * d.n_slots));
-                while (std::gcd<int64_t>(stride, d.n_slots) != 1) ++stride;
-            }
-            auto slot_of_item = [&](int32_t L0) {
-                const int32_t L = opt.shuffle ? int32_t((int64_t(L0) * stride) % d.n_slots) : L0;
-                return balance ? spt * (L % nq) + L / nq : L;
-            };
+            const uint32_t RB = uint32_t(d.rec_base);
+            // item L (owned tets first, Morton order each) -> slot: lane L % nq takes it as its (L / nq)-th slot, so that the owned
+            // and the halo items are spread evenly over the lanes and `owned` is all but wave-uniform per position
+            auto slot_of_item = [&](int32_t L) { return spt * (L % nq) + L / nq; };
             auto item_tet = [&](int32_t L) { return L < d.n_owned ? own[size_t(L)] : halo[size_t(L - d.n_owned)]; };
             for (int32_t L = 0; L < d.n_slots; ++L) {
                 int32_t el = item_tet(L);
@@ -789,10 +832,9 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 std::memset(pl, 0, size_t(blob_end - d.blob_off));
                 std::fill_n(P.slot_tet.data() + P.slot_base[size_t(t)], size_t(d.s_pad), int32_t(-1));
             }
-            const uint32_t ZS = uint32_t(d.s_pad);
-            // padding slots: lv = 0, neighbours = the slot itself, dminv = 0 (F = 0, forces = 0, no incidence entries)
+            // padding slots: lv = 0, neighbours = the slot itself, dminv = 0 (F = 0; they write no forces: the kernels stop at n_slots)
             for (int32_t s = 0; s < d.s_pad; ++s) {
-                const uint32_t f = record_token(uint32_t(lds_index(s, nq, spt)));
+                const uint32_t f = record_token(uint32_t(lds_index(s, nq, spt)), RB);
                 pl[2 * size_t(d.s_pad) + s] = f | (f << 16);
                 pl[3 * size_t(d.s_pad) + s] = f | (f << 16);
             }
@@ -802,10 +844,7 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 const int32_t s = slot_of_item(L);
                 const bool owned = L < d.n_owned;
                 stet[s] = el;
-                uint32_t lv[4], nb[4];
-                // local vertices as byte offsets into the staged float4 positions (16 B each)
-                for (int a = 0; a < 4; ++a) lv[a] = uint32_t(S.vert_local[tets[4 * int64_t(el) + a]]) << 4;
-                if (owned) lv[0] |= kOwnedBit;
+                uint32_t nb[4];
                 // neighbour k as an LDS record index; a face without a usable neighbour points at the slot itself
                 const uint32_t self = uint32_t(lds_index(s, nq, spt));
                 for (int k = 0; k < 4; ++k) {
@@ -836,10 +875,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                         if (n_planes == kPlanesWeighted) putf(18 + k, wc);
                     }
                 }
-                pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
-                pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
-                pl[2 * size_t(d.s_pad) + s] = record_token(nb[0]) | (owned ? kOwnedBit : 0u) | (record_token(nb[1]) << 16);
-                pl[3 * size_t(d.s_pad) + s] = record_token(nb[2]) | (record_token(nb[3]) << 16);
+                pl[2 * size_t(d.s_pad) + s] = record_token(nb[0], RB) | (record_token(nb[1], RB) << 16);
+                pl[3 * size_t(d.s_pad) + s] = record_token(nb[2], RB) | (record_token(nb[3], RB) << 16);
                 // Dm^-1 in double from the fp32 rest positions, rounded to fp32
                 const int32_t *tt = tets + 4 * int64_t(el);
                 double D[9];
@@ -868,6 +905,38 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                             std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
                         }
             }
+            // ---- vertex fields: local vertex + the slot's rank at it, handed out in SLOT order (= the order of the per-vertex sum) ----
+            for (int32_t s = 0; s < d.s_pad; ++s) {
+                if (stet[s] < 0) continue;
+                uint32_t lv[4];
+                for (int a = 0; a < 4; ++a) {
+                    int32_t i = S.vert_local[tets[4 * int64_t(stet[s]) + a]];
+                    while (next_rank[size_t(i)] >= tdeg[size_t(i)]) i = copy_of[size_t(i)];   // this copy is full: the hub's next one
+                    lv[a] = uint32_t(i) | (uint32_t(next_rank[size_t(i)]++) << kRankShift);
+                }
+                pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
+                pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
+            }
+            // ---- row table: row r = the vertices met by more than r slots, a prefix of the (sorted) tile vertices ----
+            {
+                uint16_t *rt = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(pl) + tile_rowtab_offset(n_planes, d.s_pad));
+                int32_t start = 0, width = d.n_verts;
+                for (int32_t r = 0; r < kRowTabEntries; ++r) {
+                    rt[r] = uint16_t(start);
+                    while (width > 0 && tdeg[size_t(width) - 1] <= r) --width;
+                    start += width;
+                }
+                if (rebuild) {   // the tile's rest positions, tile vertex order, one float4 each
+                    float *rp = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(pl) + tile_rest_offset(n_planes, d.s_pad));
+                    for (int32_t v = 0; v < d.n_verts; ++v) {
+                        const int32_t gv = tv[size_t(v)];
+                        rp[4 * v + 0] = rest[3 * size_t(gv) + 0];
+                        rp[4 * v + 1] = rest[3 * size_t(gv) + 1];
+                        rp[4 * v + 2] = rest[3 * size_t(gv) + 2];
+                        rp[4 * v + 3] = 0.f;
+                    }
+                }
+            }
             // ---- LDS bank-conflict-aware neighbour order ----
             // A wave reads neighbour k of 16 lanes' tets with one ds_read_b128 per 16-lane group; two lanes
             // collide when their records share a 16-byte bank column, i.e. when the record indices agree
@@ -890,10 +959,10 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 if (tl >= nq) continue;
                                 const int32_t sl = spt * tl + pp;
                                 lane_slot[nl] = sl;
-                                cand[nl][0] = token_record(p2[sl] & kNbMask);
-                                cand[nl][1] = token_record((p2[sl] >> 16) & kNbMask);
-                                cand[nl][2] = token_record(p3[sl] & kNbMask);
-                                cand[nl][3] = token_record((p3[sl] >> 16) & kNbMask);
+                                cand[nl][0] = token_record(p2[sl] & 0xffffu, RB);
+                                cand[nl][1] = token_record(p2[sl] >> 16, RB);
+                                cand[nl][2] = token_record(p3[sl] & 0xffffu, RB);
+                                cand[nl][3] = token_record(p3[sl] >> 16, RB);
                                 ++nl;
                             }
                             uint32_t chosen[16][4];
@@ -903,8 +972,8 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                                 for (int step = 0; step < 4; ++step) chosen[li][step] = cand[li][from[li][step]];
                             for (int li = 0; li < nl; ++li) {
                                 const int32_t sl = lane_slot[li];
-                                p2[sl] = (p2[sl] & kOwnedBit) | record_token(chosen[li][0]) | (record_token(chosen[li][1]) << 16);
-                                p3[sl] = record_token(chosen[li][2]) | (record_token(chosen[li][3]) << 16);
+                                p2[sl] = record_token(chosen[li][0], RB) | (record_token(chosen[li][1], RB) << 16);
+                                p3[sl] = record_token(chosen[li][2], RB) | (record_token(chosen[li][3], RB) << 16);
                                 if (weighted)
                                     for (int base_plane : {14, 18}) {
                                         if (base_plane + 4 > n_planes) continue;   // (symmetric operator: no column-weight planes)
@@ -916,214 +985,13 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                             }
                         }
             }
-
-            // vertex incidence lists (the gradient is gathered per vertex, in this fixed order)
-            {
-                uint16_t *inc = reinterpret_cast<uint16_t *>(pl + size_t(n_planes) * size_t(d.s_pad));
-                uint16_t *inc_off = inc + 4 * size_t(d.n_inc4);
-                std::vector<int32_t> cnt(size_t(d.n_verts), 0);
-                for (int32_t sl = 0; sl < d.s_pad; ++sl) {
-                    if (stet[sl] < 0) continue;
-                    for (int a = 0; a < 4; ++a) ++cnt[size_t(S.vert_local[tets[4 * int64_t(stet[sl]) + a]])];
-                }
-                int32_t chunk = 0;
-                std::vector<int32_t> cur(size_t(d.n_verts), 0);
-                for (int32_t v = 0; v < d.n_verts; ++v) {
-                    inc_off[v] = uint16_t(chunk);
-                    cur[size_t(v)] = 4 * chunk;
-                    chunk += (cnt[size_t(v)] + 3) / 4;
-                }
-                inc_off[d.n_verts] = uint16_t(chunk);
-                if (rebuild) {   // the tile's rest positions, tile vertex order, one float4 each
-                    float *rp = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(pl) +
-                                                          tile_rest_offset(n_planes, d.s_pad, d.n_inc4, d.n_verts));
-                    for (int32_t v = 0; v < d.n_verts; ++v) {
-                        const int32_t gv = tv[size_t(v)];
-                        rp[4 * v + 0] = rest[3 * size_t(gv) + 0];
-                        rp[4 * v + 1] = rest[3 * size_t(gv) + 1];
-                        rp[4 * v + 2] = rest[3 * size_t(gv) + 2];
-                        rp[4 * v + 3] = 0.f;
-                    }
-                }
-                const uint16_t pad = uint16_t((ZS << 2) | 1u);
-                for (int64_t i = 0; i < 4 * int64_t(d.n_inc4); ++i) inc[i] = pad;
-                for (int32_t sl = 0; sl < d.s_pad; ++sl) {  // slot-major fill => each list is sorted by slot
-                    if (stet[sl] < 0) continue;
-                    for (int a = 0; a < 4; ++a) {
-                        int32_t v = S.vert_local[tets[4 * int64_t(stet[sl]) + a]];
-                        inc[cur[size_t(v)]++] = uint16_t((uint32_t(lds_index(sl, nq, spt)) << 2) | uint32_t(a));
-                    }
-                }
-                // Conflict-aware order inside every list.  The kernel gives the first K2 vertices two lanes each
-                // (lanes 2v, 2v+1 take the even / odd 4-entry chunks) and the others one lane (vertex_gather_lanes).
-                // One ds_read_b32 serves a 32-lane group (bank = (3 * entry + c) mod 32 for the float at byte
-                // 12 * entry + 4 c): at step (j, q) lane (v, h, stride) reads list position 4 (h + stride j) + q of its
-                // vertex, and two lanes collide when their entries agree mod 32.  List order is free (it only fixes
-                // the summation order): per group and step, hand every lane a not yet placed entry of its vertex with
-                // an unused residue.
-                if (opt.conflict_aware) {
-                    const int32_t K2 = vertex_two_lane_count(d.n_verts, P.block_threads);
-                    const int32_t n_lanes = std::min<int32_t>(2 * K2 + (d.n_verts - K2), std::max(P.block_threads, 2 * K2));
-                    std::vector<uint8_t> placed(4 * size_t(d.n_inc4) + 8, 0), step_taken(4 * size_t(d.n_inc4) + 8, 0);
-                    for (int32_t l0 = 0; l0 < n_lanes; l0 += 32) {
-                        const int32_t l1 = std::min<int32_t>(l0 + 32, n_lanes);
-                        int32_t steps = 0;
-                        auto lane_of = [&](int32_t L, int32_t &v, int32_t &h, int32_t &stride) {
-                            if (L < 2 * K2) {
-                                v = L >> 1, h = L & 1, stride = 2;
-                            } else {
-                                v = K2 + (L - 2 * K2), h = 0, stride = 1;
-                            }
-                        };
-                        for (int32_t L = l0; L < l1; ++L) {
-                            int32_t v, h, stride;
-                            lane_of(L, v, h, stride);
-                            const int32_t chunks = (cnt[size_t(v)] + 3) / 4;
-                            steps = std::max(steps, (chunks - h + stride - 1) / stride);
-                        }
-                        // One step = one ds_read of every lane of the group.  Which of its not yet placed entries a
-                        // lane reads in this step is a bipartite matching problem, lanes x bank residues: a MAXIMUM
-                        // matching (augmenting paths) serves the most lanes without a collision; a lane left over takes
-                        // the entry whose residue is least loaded so far.
-                        for (int32_t j = 0; j < steps; ++j)
-                            for (int32_t q = 0; q < 4; ++q) {
-                                int32_t nl = 0, lane_v[32], lane_pos[32], lane_len[32];
-                                for (int32_t L = l0; L < l1; ++L) {
-                                    int32_t v, h, stride;
-                                    lane_of(L, v, h, stride);
-                                    const int32_t pos = 4 * (h + stride * j) + q, len = cnt[size_t(v)];
-                                    if (pos >= len) continue;
-                                    lane_v[nl] = v, lane_pos[nl] = pos, lane_len[nl] = len, ++nl;
-                                }
-                                int32_t owner[32], pick[32];   // residue -> lane index, lane index -> list position
-                                for (auto &o : owner) o = -1;
-                                for (int32_t i = 0; i < nl; ++i) pick[i] = -1;
-                                // (the two lanes of a two-lane vertex share one list: an entry taken by the partner in this
-                                // step is skipped through `taken`)
-                                std::vector<uint8_t> &taken = step_taken;
-                                auto entry_free = [&](int32_t i, int32_t c) {
-                                    return !placed[4 * size_t(inc_off[lane_v[i]]) + size_t(c)] && !taken[4 * size_t(inc_off[lane_v[i]]) + size_t(c)];
-                                };
-                                // candidate entries of every lane (not yet placed), gathered once per step
-                                int32_t nc[32];
-                                uint16_t cand_c[32][64];   // list positions: a hub vertex has more than 255 incident slots
-                                uint8_t cand_r[32][64];
-                                for (int32_t i = 0; i < nl; ++i) {
-                                    const uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
-                                    const uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[lane_v[i]]);
-                                    int32_t k = 0;
-                                    for (int32_t c = 0; c < lane_len[i] && k < 64; ++c)
-                                        if (!pl_v[c]) cand_c[i][k] = uint16_t(c), cand_r[i][k] = uint8_t(lst[c] & 31), ++k;
-                                    nc[i] = k;
-                                }
-                                struct Matcher {
-                                    int32_t *owner, *pick;
-                                    const int32_t *nc, *lane_v;
-                                    const uint16_t (*cand_c)[64];
-                                    const uint8_t (*cand_r)[64];
-                                    uint8_t *taken;
-                                    const uint16_t *inc_off;
-                                    bool seen[32];
-                                    bool aug(int32_t li)   // augmenting path from lane li (DFS over at most 32 residues)
-                                    {
-                                        uint8_t *tk = taken + 4 * size_t(inc_off[lane_v[li]]);
-                                        for (int32_t k = 0; k < nc[li]; ++k) {
-                                            const int32_t c = cand_c[li][k], r = cand_r[li][k];
-                                            if (seen[r]) continue;
-                                            // an entry of a shared list may be held by the partner lane: not available
-                                            if (tk[c] && pick[li] != c) continue;
-                                            seen[r] = true;
-                                            if (owner[r] < 0 || aug(owner[r])) {
-                                                if (pick[li] >= 0) tk[pick[li]] = 0;
-                                                owner[r] = li;
-                                                pick[li] = c;
-                                                tk[c] = 1;
-                                                return true;
-                                            }
-                                        }
-                                        return false;
-                                    }
-                                } M{owner, pick, nc, lane_v, cand_c, cand_r, taken.data(), inc_off, {}};
-                                for (int32_t i = 0; i < nl; ++i) {
-                                    std::memset(M.seen, 0, sizeof(M.seen));
-                                    M.aug(i);
-                                }
-                                int32_t load[32] = {};
-                                for (int32_t r = 0; r < 32; ++r)
-                                    if (owner[r] >= 0) load[r] = 1;
-                                for (int32_t i = 0; i < nl; ++i) {
-                                    uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
-                                    if (pick[i] < 0) {   // no collision-free entry left for this lane: least loaded residue
-                                        int32_t best = -1;
-                                        for (int32_t c = 0; c < lane_len[i]; ++c)
-                                            if (entry_free(i, c) && (best < 0 || load[lst[c] & 31] < load[lst[best] & 31])) best = c;
-                                        pick[i] = best;
-                                        taken[4 * size_t(inc_off[lane_v[i]]) + size_t(best)] = 1;
-                                        ++load[lst[best] & 31];
-                                    }
-                                }
-                                // commit: move every picked entry to the position its lane reads in this step
-                                for (int32_t i = 0; i < nl; ++i) {
-                                    uint16_t *lst = inc + 4 * size_t(inc_off[lane_v[i]]);
-                                    uint8_t *pl_v = placed.data() + 4 * size_t(inc_off[lane_v[i]]);
-                                    uint8_t *tk_v = taken.data() + 4 * size_t(inc_off[lane_v[i]]);
-                                    int32_t c = pick[i];
-                                    const int32_t pos = lane_pos[i];
-                                    if (c != pos) {
-                                        // the entry sitting at `pos` may itself be another lane's pick of this step (partner
-                                        // lane of the same list): keep the bookkeeping consistent through the swap
-                                        for (int32_t k = i + 1; k < nl; ++k)
-                                            if (lane_v[k] == lane_v[i] && pick[k] == pos) pick[k] = c;
-                                        std::swap(lst[pos], lst[c]);
-                                        std::swap(tk_v[pos], tk_v[c]);
-                                    }
-                                    pl_v[pos] = 1;
-                                    tk_v[pos] = 0;
-                                }
-                            }
-                    }
-                }
-            }
         }
     });
-    timer.lap("pass B (planes, colouring, incidence matching)");
+    timer.lap("pass B (planes, ranks, colouring)");
     if (singular.load()) {
         err = "singular (zero-volume) rest tetrahedron";
         return ERR_BAD_MESH;
     }
-
-    // ---- finish lists: every vertex not owned by exactly one tile ----
-    {
-        std::vector<int32_t> fin_of(static_cast<size_t>(n), -1);
-        int64_t entries = 0;
-        for (int64_t v = 0; v < n; ++v) {
-            int32_t c = vcount[size_t(v)].load(std::memory_order_relaxed);
-            if (c == 1) continue;
-            fin_of[size_t(v)] = int32_t(P.fin_vid.size());
-            P.fin_vid.push_back(int32_t(v));
-            P.fin_off.push_back(int32_t(entries));
-            entries += c;
-            if (entries >= (int64_t(1) << 31)) {
-                err = "too many shared vertex copies for 32-bit offsets";
-                return ERR_TILING;
-            }
-        }
-        P.fin_off.push_back(int32_t(entries));
-        P.fin_idx.assign(size_t(entries), 0);
-        std::vector<int32_t> cur(P.fin_off.begin(), P.fin_off.end() - 1);
-        for (int64_t t = 0; t < T; ++t) {
-            const TileDesc &d = P.tiles[size_t(t)];
-            for (int32_t i = d.n_excl; i < d.n_verts; ++i) {
-                int32_t v = P.gvid[size_t(d.vert_off) + size_t(i)];
-                int32_t k = fin_of[size_t(v)];
-                // vertex-major staging: the copies of one vertex occupy consecutive rows, in tile order
-                // (tile-major rows + a gather in the finish kernel was measured: tile kernel unchanged,
-                // finish kernel 0.046 -> 0.084 ms)
-                P.fin_idx[size_t(d.stage_off + (i - d.n_excl))] = cur[size_t(k)]++;
-            }
-        }
-    }
-    timer.lap("finish lists");
     return OK;
 }
 

@@ -24,45 +24,49 @@
 namespace tsamd {
 
 struct PlanOptions {
-    // Defaults = the measured optimum on MI355X (profiles/README.md): two 768-thread workgroups per
-    // CU, 2 tets per lane, 80 KiB of LDS each -- 24 waves per CU hide the LDS-gather latency that one
-    // 1024-thread / 160 KiB workgroup (4 tets per lane) leaves exposed.
+    // Defaults = the measured optimum on MI355X for large batches: two 768-thread workgroups per CU, 2 tets per lane, 80 KiB of
+    // LDS each.
     int lds_budget = 0;           // bytes of LDS one workgroup may use; 0 = 80 KiB
     int max_threads = 0;          // workgroup size cap (multiple of 64, <= kTileThreads); 0 = 768
     int target_owned = 0;         // 0 = auto
-    int balance = 1;              // interleave owned / halo slots over lanes
     int num_threads = 0;          // 0 = hardware concurrency
-    int shuffle = 0;              // experiment: scatter a tile's tets over its lanes instead of Morton order
-    int conflict_aware = 1;       // order neighbour / incidence entries to dodge LDS bank conflicts
+    int conflict_aware = 1;       // order the neighbour entries to dodge LDS bank conflicts
     int rebuild_dminv = 0;        // 1 = do not stream Dm^-1 (36 of the 52 bytes per slot): keep each tile's REST positions
                                   // (16 B per tile vertex) and invert Dm in registers, in fp32 (see kPlanesRebuild)
+    int slots_per_lane = 0;       // 0 = kSlotsPerLane (2); 3 and 4 select the kernels built for fewer, fatter waves
 };
 
 // Device-visible tile descriptor (48 bytes, uniform loads in the kernel).
 struct TileDesc {
-    uint64_t blob_off;   // byte offset of the tile's 13 dword planes in the blob
+    uint64_t blob_off;   // byte offset of the tile's dword planes in the blob
     int32_t n_slots;     // owned + halo tets
     int32_t n_owned;
-    int32_t s_pad;       // n_slots rounded up to a multiple of 4 (= plane length in dwords)
-    int32_t n_verts;     // local vertices
-    int32_t n_excl;      // the first n_excl local vertices belong to this tile alone
-    int32_t vert_off;    // offset into gvid[]
-    int64_t stage_off;   // row offset into the staging buffer for the shared vertices
-    int32_t n_inc4;      // vertex-incidence list length in 4-entry (8 B) chunks
-    int32_t reserved;
+    int32_t s_pad;       // n_slots rounded up to a multiple of the lane layout (= plane length in dwords)
+    int32_t n_verts;     // local vertices (a vertex met by more than kMaxRank slots of the tile counts once per kMaxRank)
+    int32_t n_excl;      // how many of them belong to this tile alone (statistics: the kernels read the sign of vdst[])
+    int32_t vert_off;    // offset into gvid[] / vdst[] (= tile * vert_stride)
+    int64_t stage_off;   // host bookkeeping: the tile's first entry in fin_idx[]
+    int32_t n_rows;      // rows of the tile's force array = the largest number of slots any of its vertices meets (<= kMaxRank)
+    int32_t rec_base;    // LDS byte address of record 0 (tile_rec_base)
 };
 static_assert(sizeof(TileDesc) == 48, "TileDesc layout is part of the kernel ABI");
 
 // Per tile, in this order, inside the blob:
 //   13 planes of s_pad dwords : lv01, lv23, nb01, nb23, dminv[9]        (tet-slot major, 52 B / slot)
-//   n_inc4 chunks of 4 x u16  : vertex incidence entries (LDS record index << 2 | local vertex a), grouped by
-//                               local vertex, each vertex padded to whole chunks with (zero slot, a=1)
-//   n_verts + 1 x u16         : first chunk of every local vertex
+//   kRowTabEntries x u16      : row_start[r], r = 0 .. n_rows (the rest repeats the total): where row r of the tile's
+//                               per-vertex force array begins, in 12-byte entries
+//   (rebuild_dminv plans)     : one float4 per tile vertex, 16-byte aligned, behind the row table
+// That is ALL an evaluation streams per slot: since round 5 there are no per-vertex incidence lists (8.6 bytes per slot until
+// round 4).  The forces of a tile are summed per vertex through a "jagged diagonal" array instead: the tile's vertices are
+// numbered by falling slot count, entry (v, r) -- the r-th slot that meets vertex v -- sits at row_start[r] + v, so row r is
+// the contiguous run of the vertices met by more than r slots.  A slot SCATTERS its four corner forces (the rank r of each
+// corner rides in the six spare bits of its 16-bit vertex field), a lane per vertex then walks the rows: consecutive lanes read
+// consecutive 12-byte entries -- no list, no index arithmetic beyond one add, no bank conflict.
 constexpr int kPlanes = 13;
-// Lane layout the kernels are compiled for: two consecutive slots per lane (one 8-byte load per plane), workgroups of
-// at most 768 threads (80-VGPR builds, also with an explicit operator: 78 VGPRs, no spill): two workgroups per CU
-// when a tile's LDS is <= 80 KiB.  (Round 2 ran explicit-operator plans on 512-thread / 54 400 B tiles with a
-// 92-VGPR kernel: 0.0942 ms on 64 x kuhn19 against 0.0836 ms for this layout, built-in operator 0.0593 ms.)
+constexpr int kRowTabEntries = 72;                 // u16 each; 144 bytes keep what follows 16-byte aligned
+constexpr int kMaxRank = 64;                       // slots per (virtual) tile vertex: 6-bit rank
+// Lane layout the default kernels are compiled for: two consecutive slots per lane (one 8-byte load per plane), workgroups of
+// at most 768 threads (80-VGPR builds, also with an explicit operator): two workgroups per CU when a tile's LDS is <= 80 KiB.
 constexpr int kSlotsPerLane = 2;
 constexpr int kTileThreads = 768;
 // Plans built with an explicit element operator (build_plan's `op`) carry 9 more fp32 planes per slot:
@@ -77,61 +81,61 @@ constexpr int kPlanesWeighted = 22;
 // pass 3 applies L^T = L with the row weights it already holds.
 constexpr int kPlanesWeightedSym = 18;
 // Plans built with rebuild_dminv carry only the four index planes (16 bytes per slot instead of 52) and, behind the
-// incidence offsets (16-byte aligned), one float4 per tile vertex with its REST position; the kernels stage those next
+// row table, one float4 per tile vertex with its REST position; the kernels stage those next
 // to the current positions and rebuild Dm^-1 = cofactor^T / det per slot in fp32 registers.  This is NOT bit-identical
 // to the streamed operator (built in double and rounded to fp32 like the reference's matrices, tet_spheres.cpp:43-45):
 // entries differ by <= 2.8e-7 relative (mean 2.7e-8) against 5.9e-8 (mean 1.1e-8) for the rounding itself, and the
 // gradient moves by ~7e-8 relative (profiles/r02_experiments.md).  Not combined with an explicit operator.
 constexpr int kPlanesRebuild = 4;
 // Index planes, two 16-bit fields per dword:
-//   lv01 = (16 * v0 | owned << 15) | (16 * v1) << 16      vertex ids pre-multiplied to byte offsets
-//   lv23 = (16 * v2)               | (16 * v3) << 16      into the staged float4 positions
-//   nb01 = (f0 | owned << 15)      | f1 << 16             f = record_token(LDS record index of the face neighbour):
-//   nb23 =  f2                     | f3 << 16             a quarter of the byte address of the record's ninth entry
+//   lv01 = (v0 | r0 << 10) | (v1 | r1 << 10) << 16     v = local vertex (< 1024), r = rank of this slot among the slots that
+//   lv23 = (v2 | r2 << 10) | (v3 | r3 << 10) << 16     meet v (< 64): the corner's force goes to entry row_start[r] + v
+//   nb01 =  f0 | f1 << 16                              f = record_token(LDS record index of the face neighbour): a quarter of
+//   nb23 =  f2 | f3 << 16                              the byte address of the record's ninth entry (16 bits: any LDS address)
 // A face without a neighbour in the tile (mesh boundary; for halo slots: any neighbour that is not owned by the
 // tile) points at the slot's OWN record: the kernels evaluate 4 * own - sum of the four, so such a face adds
 // own - own = 0 and neither a degree nor a dummy record is needed.
-constexpr uint32_t kOwnedBit = 0x8000u;
-constexpr uint32_t kNbMask = 0x7fffu;
-// LDS record of index idx: 48 bytes at 48 * idx = [tail quad | entries 0..3 | entries 4..7]; the ninth matrix entry
+// There is no "owned" bit any more: lane t's p-th slot is item p * nq + t of the tile (nq = s_pad / slots per lane) and the
+// items below n_owned are the owned ones, so a lane compares its item number with the descriptor's n_owned.
+constexpr uint32_t kVertMask = 0x3ffu;
+constexpr int kRankShift = 10;
+constexpr int kMaxTileVerts = 1023;
+// LDS map of a tile (absolute byte addresses; the kernels' only LDS object is the dynamic array at address 0):
+//   [0, 320)                 row table as u32 byte addresses (65 entries used)
+//   [320, 320 + 16 VP)       staged positions, one float4 per local vertex (VP = vertices rounded up to 4)
+//   (+ 16 VP)                rebuild_dminv plans: the staged rest positions
+//   + 256                    reduction scratch
+//   rec_base ...             one 48-byte record per slot: F, later H; then, over the same bytes, the force array
+//                            (12 bytes per (vertex, slot) incidence = 48 per slot)
+constexpr int kRowTabBytes = 320;
+inline int64_t tile_rec_base(int64_t n_verts, bool rebuild_dminv = false)
+{
+    const int64_t vp = (n_verts + 3) & ~int64_t(3);
+    return kRowTabBytes + (rebuild_dminv ? 32 : 16) * vp + 256;
+}
+// LDS record of index idx: 48 bytes at rec_base + 48 * idx = [tail quad | entries 0..3 | entries 4..7]; the ninth matrix entry
 // sits in the tail quad at dword (idx >> 3) & 3 -- rotating it with bits 3-4 of the index spreads the 4-byte
 // gathers of it over all 32 banks (at a fixed position the 48-byte stride folds them onto 8).  The token
-// 12 * idx + rot is what the planes store: token << 2 is the byte address of the ninth entry, and that address
+// rec_base / 4 + 12 * idx + rot is what the planes store: token << 2 is the byte address of the ninth entry, and that address
 // with its low four bits cleared is the record base -- one shift and one mask per gathered record.
-inline uint32_t record_token(uint32_t idx) { return 12u * idx + ((idx >> 3) & 3u); }
-inline uint32_t token_record(uint32_t token) { return token / 12u; }
-constexpr int kMaxTileVerts = 2047;
-// Lanes of the per-vertex force gather: with n_verts vertices and nthr lanes, the first K2 vertices of the tile
-// (the ones with the longest incidence lists come first) get two lanes each -- lanes 2v, 2v+1 take the even / odd
-// chunks of the list -- and the other n_verts - K2 one lane each, so that every vertex is served in ONE round and
-// no lane walks a second vertex (round 1: two lanes for everybody, the first 2 n_verts - nthr lanes then took a
-// second vertex, cold, while eleven of the twelve waves waited for them).
-TSAMD_HOST_DEVICE inline int32_t vertex_two_lane_count(int32_t n_verts, int32_t nthr)
-{
-    return n_verts <= nthr ? (n_verts < nthr - n_verts ? n_verts : nthr - n_verts) : 0;
-}
+inline uint32_t record_token(uint32_t idx, uint32_t rec_base) { return rec_base / 4u + 12u * idx + ((idx >> 3) & 3u); }
+inline uint32_t token_record(uint32_t token, uint32_t rec_base) { return (token - rec_base / 4u) / 12u; }
 
 // Where slot s (HBM plane order: thread t streams slots spt*t .. spt*t+spt-1 as one load per plane) lives in
 // the LDS planes.  Lane t keeps its p-th slot at p * nq + t, so the 64 lanes of a wave touch 64
 // consecutive float4 -- conflict-free -- instead of a 64 B stride (4-way bank conflict, measured:
-// 70 % of all LDS cycles).  Neighbour and incidence entries in the blob hold these LDS indices.
+// 70 % of all LDS cycles).  Neighbour entries in the blob hold these LDS indices (as tokens).
 inline int32_t lds_index(int32_t slot, int32_t nq, int32_t spt) { return (slot % spt) * nq + slot / spt; }
 
-// LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices:
-// 48 B per slot (F as 9 floats + 3 pad, later H, later the 4 x 3 vertex forces), + the zero slot,
-// 16 B per staged vertex position, 256 B of reduction scratch.
+// LDS bytes the kernels carve for a tile with padded slot count s_pad and n_verts vertices.
 inline int64_t tile_lds_bytes(int64_t s_pad, int64_t n_verts, bool rebuild_dminv = false)
 {
-    const int64_t sa = s_pad + 4;
-    const int64_t vp = (n_verts + 3) & ~int64_t(3);
-    return 48 * sa + (rebuild_dminv ? 32 : 16) * vp + 256;   // (+ the staged rest positions)
+    return tile_rec_base(n_verts, rebuild_dminv) + 48 * s_pad;
 }
 
-// Byte offset, inside a tile's blob, of the float4 rest positions of a rebuild_dminv plan.
-inline int64_t tile_rest_offset(int64_t n_planes, int64_t s_pad, int64_t n_inc4, int64_t n_verts)
-{
-    return (n_planes * s_pad * 4 + n_inc4 * 8 + 2 * (n_verts + 1) + 15) & ~int64_t(15);
-}
+// Byte offsets, inside a tile's blob, of the row table and of the float4 rest positions of a rebuild_dminv plan.
+inline int64_t tile_rowtab_offset(int64_t n_planes, int64_t s_pad) { return n_planes * s_pad * 4; }
+inline int64_t tile_rest_offset(int64_t n_planes, int64_t s_pad) { return tile_rowtab_offset(n_planes, s_pad) + 2 * kRowTabEntries; }
 
 // std::vector whose resize() leaves trivially-constructible elements uninitialised: the plan's big arrays (hundreds of MB
 // at 21 M tets) are then first touched -- and zero-filled where needed -- by the worker threads that fill them, not by
@@ -161,6 +165,8 @@ struct Plan {
     std::vector<TileDesc> tiles;
     RawVector<uint32_t> blob;        // all tiles' planes
     RawVector<int32_t> gvid;         // all tiles' local->global vertex ids
+    RawVector<int32_t> vdst;         // same layout: where the tile's sum for that vertex goes -- >= 0: row of grad (the vertex
+                                     // belongs to this tile alone), < 0: staging row ~vdst (summed by the finish kernel)
     RawVector<int32_t> slot_tet;     // per tile s_pad entries, global tet id or -1 (host only)
     std::vector<int64_t> slot_base;  // per tile offset into slot_tet
     // finish vertex k (global id fin_vid[k]) = sum of staging rows [fin_off[k], fin_off[k+1]);

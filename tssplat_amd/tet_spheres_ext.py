@@ -93,7 +93,7 @@ class TetSpheres:
 
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
-                 balance_slots: bool = True, num_threads: int = 0, debug_shuffle: int = 0,
+                 num_threads: int = 0, debug_flags: int = 0,
                  slots_per_thread: int = 0, operator=None, rebuild_dminv: bool | None = None):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
@@ -113,8 +113,8 @@ class TetSpheres:
         opts = _capi.make_options(device=-1 if self.device is None else self.device.index,
                                   host_only=int(host_only), lds_budget_bytes=lds_budget_bytes,
                                   max_threads=max_threads, target_owned=target_owned,
-                                  balance_slots=int(balance_slots), num_threads=num_threads,
-                                  debug_shuffle=int(debug_shuffle), slots_per_thread=slots_per_thread,
+                                  num_threads=num_threads,
+                                  debug_flags=int(debug_flags), slots_per_thread=slots_per_thread,
                                   # (the environment default only applies where it can; an explicit True that cannot be
                                   # honoured -- together with operator= -- is rejected by the library, not ignored)
                                   rebuild_dminv=int(REBUILD_DMINV and operator is None) if rebuild_dminv is None
