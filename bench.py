@@ -58,7 +58,8 @@ def parse(argv=None):
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=50)
     p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--scene", default="kuhn19", help="kuhnK | cone | delaunayN (per-sphere template)")
+    p.add_argument("--scene", default="kuhn19", help="kuhnK | cone | delaunayN | aveg (per-sphere template; aveg = the reference's a.veg, "
+                   "952 of them make the headline's 21 M tets)")
     p.add_argument("--spheres", type=int, default=512, help="spheres per job (strong) / per rank (weak)")
     p.add_argument("--sigma", type=float, default=0.02, help="deformation noise, fraction of sphere radius")
     p.add_argument("--order", type=int, default=2)
@@ -233,16 +234,20 @@ def _run_rank(args, stdout_fd: int) -> None:
         from tssplat_amd.sharding import partition_spheres
 
     # ---- the spheres this rank owns (whole spheres, contiguous, balanced on tet count) ----
+    v_range = None
     if scaling == "weak":
         my_spheres, total_spheres, seed = args.spheres, args.spheres * world, 1000 * rank
         sc = scenes.make_scene(args.scene, my_spheres, seed=seed) if use_gpu else None
     else:
         total_spheres = args.spheres
         if use_gpu:
-            full = scenes.make_scene(args.scene, total_spheres, seed=0)
-            lo, hi = partition_spheres(list(map(int, (full.sphere_tet_offsets[1:] - full.sphere_tet_offsets[:-1]))), world)[rank]
-            sc = full.slice_spheres(lo, hi)
-            del full
+            # every rank builds ONLY its own spheres (same radii / centres / noise as in the full scene: scenes.make_scene's
+            # sphere_range, scenes.deform's vertex_range) -- eight ranks on one host do not each generate the 21 M-tet batch
+            tv, tt = scenes.template_mesh(args.scene, seed=0)
+            lo, hi = partition_spheres([int(tt.shape[0])] * total_spheres, world)[rank]
+            sc = scenes.make_scene(args.scene, total_spheres, seed=0, sphere_range=(lo, hi))
+            v_range = (lo * int(tv.shape[0]), hi * int(tv.shape[0]), total_spheres * int(tv.shape[0]))
+            del tv, tt
         else:
             lo, hi = partition_spheres([1] * total_spheres, world)[rank]
             sc = None
@@ -295,7 +300,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     info = energy.tet_sp.plan_info()
     if rank == 0:
         log(f"rank 0: {my_spheres} x {args.scene}: n={sc.n_vertices} m={sc.n_tets}; plan {t_plan:.1f} s: {info}")
-    x_host = scenes.deform(sc, args.sigma, seed=seed + 1)
+    x_host = scenes.deform(sc, args.sigma, seed=seed + 1, vertex_range=v_range)
     x = torch.nn.Parameter(torch.from_numpy(x_host).to(dev))
     m_local, n_local = sc.n_tets, sc.n_vertices
     cpu_sample = None
@@ -403,6 +408,7 @@ def _run_rank(args, stdout_fd: int) -> None:
             reducer.flush()                 # the last (partial) window's collective is issued inside the timed region
         fence()
         el = time.perf_counter() - t0
+        timed.local = el
         if world > 1:
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -425,6 +431,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     main_fn = {"graph": step_graph, "eager": step_eager, "graph-autograd": step_graph_autograd}[launch_mode]
     preheat()
     elapsed, e_last = timed(main_fn, args.steps, args.warmup)
+    elapsed_local = timed.local
     e_val = float(e_last)
     # the collective's result = sum of the rank energies (checked, not just issued)
     e_global = e_val
@@ -493,6 +500,14 @@ def _run_rank(args, stdout_fd: int) -> None:
         dist.all_reduce(mt)
     total_tets = int(mt.item())
     value = total_tets * args.steps / elapsed
+    # what every rank did: its own (un-maximised) step time, its tets, its kernel times -- imbalance shows here, not in `value`
+    mine = torch.tensor([1e3 * elapsed_local / args.steps, float(m_local), tile_ms, finish_ms], device=dev, dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = [[float(v) for v in t.tolist()] for t in per_rank]
 
     out = None
     if rank == 0:
@@ -529,7 +544,13 @@ def _run_rank(args, stdout_fd: int) -> None:
                 "lds_bytes": info["lds_bytes"],
                 "parallelism": f"whole spheres sharded over {world} GPU(s); one scalar-energy all-reduce per step, "
                                f"result checked against the sum of rank energies",
+                "parity": "partial (L unpinned): the smoothness operator L is the ASSUMED uniform face-adjacency umbrella -- libpgo's "
+                          "pgo_create_tet_biharmonic_gradient_matrix (tet_spheres.cpp:148) is not in the reference; G, det, cofactor "
+                          "and the penalty are pinned to reference code; tools/pin_L_with_pypgo.py settles it where libpgo exists",
             },
+            "per_rank": {"ms_per_step": [r[0] for r in per_rank], "tets": [int(r[1]) for r in per_rank],
+                         "tile_kernel_ms": [r[2] for r in per_rank], "finish_kernel_ms": [r[3] for r in per_rank],
+                         "ms_per_step_min": min(r[0] for r in per_rank), "ms_per_step_max": max(r[0] for r in per_rank)},
             "roofline": {
                 "bound": "hbm",
                 "kernel": "tile_energy_kernel<WITH_GRAD=true>",

@@ -134,7 +134,7 @@ def test_two_ranks_match_unsharded_oracle():
 def test_single_process_is_identity():
     rest, tets, vo, to, x = _scene()
     mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
-    assert mod.exchange == "window"
+    assert mod.exchange == "step"                          # the job-wide value by default; the windowed exchange is an opt-in
     assert mod.world_size == 1 and mod.vertex_range == (0, rest.shape[0])
     xl = torch.from_numpy(x).requires_grad_(True)
     e = mod(xl, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff)
@@ -248,8 +248,8 @@ def _worker8(rank, world, port, n_spheres, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         rest, tets, vo, to, x = _scene_uneven(n_spheres)
-        # windowed exchange (the default): rank-local value per step, job-wide energies from reduced_energies()
-        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, window=4)
+        # windowed exchange (opt-in): rank-local value per step, job-wide energies from reduced_energies()
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, exchange="window", window=4)
         lo, hi = mod.vertex_range
         xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
         local, grads = [], None
@@ -260,6 +260,9 @@ def _worker8(rank, world, port, n_spheres, out):
             e.backward()
             local.append(float(e.detach()))
             grads = xl.grad.numpy().copy()
+            if rank == 0:                                    # a log line on ONE rank: under no_grad nothing is filed, the windows stay in step
+                with torch.no_grad():
+                    assert abs(float(mod(xl, it, c1 * (1 + it), c2)) - local[-1]) <= 1e-6 * abs(local[-1]) + 1e-12
         reduced = mod.reduced_energies().numpy().copy()
         # replicated-parameter mode on top of the per-step exchange
         mod2 = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, exchange="step")
@@ -324,3 +327,36 @@ def test_bench_spawns_eight_ranks_dry_run():
         assert len(lines) == 1, out.stdout
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == 8 and rec["config"]["energy_allreduce_checked"] and rec["config"]["spheres_total"] == spheres
+
+
+def test_windowed_reducer_bounds_what_it_keeps():
+    """A loop that never asks for the reduced energies must not accumulate device tensors: with max_pending the oldest
+    windows are dropped (with one warning), the newest are still delivered in order."""
+    import warnings
+    from tssplat_amd.sharding import WindowedEnergyAllReduce
+    red = WindowedEnergyAllReduce(2, "cpu", max_inflight=1, max_pending=3)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for k in range(20):
+            red.push(torch.tensor(float(k)))
+    assert any("reduced windows waiting" in str(w.message) for w in rec) and red.dropped > 0
+    got = red.results().tolist()
+    assert len(got) <= 2 * (3 + 1) + 2 and got == sorted(got) and got[-1] == 19.0
+
+
+def test_rank_scene_slices_equal_the_full_scene():
+    """bench.py builds only a rank's spheres (scenes.make_scene(..., sphere_range=...), scenes.deform(..., vertex_range=...)): they
+    must be exactly the slice of the full scene that TetScene.slice_spheres / the full deformation give."""
+    from tssplat_amd import scenes
+    from tssplat_amd.sharding import partition_spheres
+    for kind, total, world in (("kuhn3", 13, 8), ("cone", 5, 2), ("aveg", 3, 2)):
+        full = scenes.make_scene(kind, total, seed=0)
+        xf = scenes.deform(full, 0.02, seed=1)
+        tv, tt = scenes.template_mesh(kind, seed=0)
+        for lo, hi in partition_spheres([int(tt.shape[0])] * total, world):
+            part = scenes.make_scene(kind, total, seed=0, sphere_range=(lo, hi))
+            ref = full.slice_spheres(lo, hi)
+            assert np.array_equal(part.rest, ref.rest) and np.array_equal(part.tets, ref.tets)
+            assert np.array_equal(part.sphere_vertex_offsets, ref.sphere_vertex_offsets) and np.array_equal(part.radii, ref.radii)
+            v0, v1 = lo * tv.shape[0], hi * tv.shape[0]
+            assert np.array_equal(scenes.deform(part, 0.02, seed=1, vertex_range=(v0, v1, full.n_vertices)), xf[v0:v1])

@@ -270,6 +270,7 @@ struct KernelArgs {
 };
 
 constexpr uint32_t kXS = kRowTabBytes;   // LDS byte address of the staged positions (plan.h: LDS map of a tile)
+constexpr uint32_t kZeroEntry = 4u * 66u;   // three zero dwords behind the 65 row starts: what a lane without an entry in a row reads
 
 // byte offset (16 v) of a corner's staged position from its 16-bit vertex field (low / high half of a plane dword)
 __device__ __forceinline__ uint32_t pos_lo(uint32_t w) { return (w & kVertMask) << 4; }
@@ -371,7 +372,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
     }
     uint32_t row0 = 0;
-    if (WITH_GRAD && tid < 65) row0 = g_rowtab[tid];   // row table: start of row `tid` of the force array, in 12-byte entries
+    if (WITH_GRAD && tid < 72) row0 = g_rowtab[tid < 65 ? tid : 64];   // row table: start of row `tid` of the force array, in 12-byte entries
     __builtin_amdgcn_sched_barrier(0);
 
     // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
@@ -441,7 +442,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         }
     }
     // the row table as LDS byte addresses of the rows (wave 0 and lane 64; read from the scatter phase on)
-    if (WITH_GRAD && tid < 65) *lds_at<uint32_t>(4u * uint32_t(tid)) = RB + 12u * row0;
+    if (WITH_GRAD) {
+        if (tid < 72) *lds_at<uint32_t>(4u * uint32_t(tid)) = tid < 65 ? RB + 12u * row0 : 0u;   // (+ the zero entry)
+        if (nthr < 72 && tid < 8)   // a 64-thread workgroup: its first lanes write the table's tail as well
+            *lds_at<uint32_t>(256u + 4u * uint32_t(tid)) = tid == 0 ? RB + 12u * uint32_t(g_rowtab[64]) : 0u;
+    }
     __syncthreads();
 
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
@@ -633,17 +638,20 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
             const int rows = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wid > 768u * uint32_t(vb)));
             float gx = 0.f, gy = 0.f, gz = 0.f;
             // (four rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
-            // beyond the tile's last one are empty: width 0)
+            // beyond the tile's last one are empty: width 0.  Branch-free: a lane beyond a row's width reads the three zero
+            // dwords behind the row table instead, so that the four rows' reads are in flight together.)
             for (int r = 0; r < rows; r += 4) {
+                const LDS_AS float *f[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
-                    if (v12 < w) {
-                        const LDS_AS float *f = lds_at<const float>(base + v12);
-                        gx += f[0];
-                        gy += f[1];
-                        gz += f[2];
-                    }
+                    f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gx += f[u][0];
+                    gy += f[u][1];
+                    gz += f[u][2];
                 }
             }
             if (v < td.n_verts) {

@@ -91,8 +91,10 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
             if ext is not None:
                 return ext.energy_replay(x, gr.graph_address(order), c1, c2, gr.energy, gr.grad, gr.ticket_tensor)
             return GraphReplayFunc.apply(x, gr, c1, c2, order)
-        if (ext is not None and not tet_spheres_ext.cpu_energy_mode() and x.is_cuda and x.dtype == torch.float32
-                and x.numel() == self.tet_sp.n3 and x.device == self.tet_sp.device):
+        # (the extension always runs the fused forward+backward pass and allocates the gradient: only where that is what the
+        # Python path would do as well -- a differentiable input and fusion not switched off)
+        if (ext is not None and x.requires_grad and self.tet_sp.fuse_forward_backward and not tet_spheres_ext.cpu_energy_mode()
+                and x.is_cuda and x.dtype == torch.float32 and x.numel() == self.tet_sp.n3 and x.device == self.tet_sp.device):
             self.tet_sp._cache = None      # (a fused result kept by the operator functions belongs to an older evaluation now)
             return ext.energy_eval(x, int(self.tet_sp._handle().value), c1, c2, order)
         return SmoothnessBarrierFunc.apply(x, self.tet_sp, c1, c2, order)

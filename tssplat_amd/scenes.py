@@ -184,50 +184,77 @@ def delaunay_ball(n_points: int, seed: int = 0, min_quality: float = 0.08) -> tu
 
 
 def replicate_spheres(verts: np.ndarray, tets: np.ndarray, n_spheres: int,
-                      seed: int = 0) -> TetScene:
+                      seed: int = 0, sphere_range: tuple[int, int] | None = None) -> TetScene:
     """Stack ``n_spheres`` scaled/translated copies of one template tet mesh.
 
     Sphere ``s``: radius ``r_s ~ U(0.05, 0.30)``, centre ``c_s ~ U(-0.7, 0.7)^3``
-    from ``numpy.random.default_rng(seed)``.
+    from ``numpy.random.default_rng(seed)``.  ``sphere_range=(lo, hi)`` builds only the spheres
+    ``[lo, hi)`` of that batch -- same radii and centres as in the full scene, vertex ids re-based -- i.e. exactly
+    ``replicate_spheres(...).slice_spheres(lo, hi)`` without materialising the rest (what one rank of a sharded job owns).
     """
     rng = np.random.default_rng(seed)
     radii = rng.uniform(0.05, 0.30, size=n_spheres)
     centres = rng.uniform(-0.7, 0.7, size=(n_spheres, 3))
+    lo, hi = (0, n_spheres) if sphere_range is None else sphere_range
+    if not 0 <= lo <= hi <= n_spheres:
+        raise ValueError(f"sphere_range {sphere_range} outside [0, {n_spheres}]")
+    k = hi - lo
     nv, nt = verts.shape[0], tets.shape[0]
-    rest = np.empty((n_spheres * nv, 3), dtype=np.float32)
-    allt = np.empty((n_spheres * nt, 4), dtype=np.int32)
+    rest = np.empty((k * nv, 3), dtype=np.float32)
+    allt = np.empty((k * nt, 4), dtype=np.int32)
     v32 = verts.astype(np.float64)
-    for s in range(n_spheres):
-        rest[s * nv:(s + 1) * nv] = (v32 * radii[s] + centres[s]).astype(np.float32)
-        allt[s * nt:(s + 1) * nt] = tets + np.int32(s * nv)
+    for j, s in enumerate(range(lo, hi)):
+        rest[j * nv:(j + 1) * nv] = (v32 * radii[s] + centres[s]).astype(np.float32)
+        allt[j * nt:(j + 1) * nt] = tets + np.int32(j * nv)
     return TetScene(
         rest=rest,
         tets=allt,
-        sphere_vertex_offsets=np.arange(n_spheres + 1, dtype=np.int64) * nv,
-        sphere_tet_offsets=np.arange(n_spheres + 1, dtype=np.int64) * nt,
-        radii=radii,
+        sphere_vertex_offsets=np.arange(k + 1, dtype=np.int64) * nv,
+        sphere_tet_offsets=np.arange(k + 1, dtype=np.int64) * nt,
+        radii=radii[lo:hi],
     )
 
 
-def make_scene(kind: str, n_spheres: int, seed: int = 0) -> TetScene:
-    """Named workloads: ``kuhn8`` (3 072 tets/sphere), ``kuhn19`` (41 154),
-    ``kuhnK`` for any K, ``cone`` (icosphere coned to its centre), ``delaunayN`` (N random points)."""
+def template_mesh(kind: str, seed: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """The per-sphere template of a named workload: ``kuhnK``, ``cone``, ``delaunayN`` (N random points), ``aveg`` (the
+    reference's TetWild-quality fixture /root/reference/tssplat_ext/a.veg, 4 500 vertices / 22 120 tets, kept as
+    tests/golden/aveg_mesh.npz, centred and scaled into the unit ball like the other templates)."""
     if kind.startswith("kuhn"):
-        v, t = kuhn_ball(int(kind[4:]))
-    elif kind == "cone":
-        v, t = cone_sphere(*icosphere_surface(3))
-    elif kind.startswith("delaunay"):
-        v, t = delaunay_ball(int(kind[8:]), seed=seed)
-    else:
-        raise ValueError(f"unknown scene kind {kind!r}")
-    return replicate_spheres(v, t, n_spheres, seed=seed)
+        return kuhn_ball(int(kind[4:]))
+    if kind == "cone":
+        return cone_sphere(*icosphere_surface(3))
+    if kind.startswith("delaunay"):
+        return delaunay_ball(int(kind[8:]), seed=seed)
+    if kind == "aveg":
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "aveg_mesh.npz")
+        g = np.load(path)
+        v = g["rest"].astype(np.float64).reshape(-1, 3)
+        v = v - 0.5 * (v.min(axis=0) + v.max(axis=0))
+        return v / np.linalg.norm(v, axis=1).max(), _orient_positive(v, g["tets"].astype(np.int32).reshape(-1, 4))
+    raise ValueError(f"unknown scene kind {kind!r}")
 
 
-def deform(scene: TetScene, sigma: float, seed: int = 1) -> np.ndarray:
-    """``x = X_rest + sigma * r_s * N(0,1)`` in float32."""
+def make_scene(kind: str, n_spheres: int, seed: int = 0, sphere_range: tuple[int, int] | None = None) -> TetScene:
+    """Named workloads: ``kuhn8`` (3 072 tets/sphere), ``kuhn19`` (41 154), ``kuhnK`` for any K, ``cone`` (icosphere coned
+    to its centre), ``delaunayN`` (N random points), ``aveg`` (the reference's a.veg).  ``sphere_range``: see
+    :func:`replicate_spheres`."""
+    v, t = template_mesh(kind, seed)
+    return replicate_spheres(v, t, n_spheres, seed=seed, sphere_range=sphere_range)
+
+
+def deform(scene: TetScene, sigma: float, seed: int = 1, vertex_range: tuple[int, int, int] | None = None) -> np.ndarray:
+    """``x = X_rest + sigma * r_s * N(0,1)`` in float32.  ``vertex_range=(v0, v1, n_total)``: ``scene`` is the
+    slice ``[v0, v1)`` of a scene of ``n_total`` vertices -- return that slice of the FULL scene's deformed positions (the noise
+    stream is drawn for the whole batch, so that a rank's positions do not depend on how the batch is sharded)."""
     rng = np.random.default_rng(seed)
-    noise = rng.standard_normal(scene.rest.shape)
     per_vertex_r = np.repeat(scene.radii, np.diff(scene.sphere_vertex_offsets))
+    if vertex_range is None:
+        noise = rng.standard_normal(scene.rest.shape)
+    else:
+        v0, v1, n_total = vertex_range
+        if v0:
+            rng.standard_normal((v0, 3))             # (advance the stream; block-wise to bound memory)
+        noise = rng.standard_normal((v1 - v0, 3))
     return (scene.rest.astype(np.float64) + sigma * per_vertex_r[:, None] * noise).astype(np.float32)
 
 

@@ -124,10 +124,11 @@ class WindowedEnergyAllReduce:
     With one rank or no initialised process group the collective is the identity; everything else runs unchanged.
     """
 
-    def __init__(self, window: int, device, group=None, max_inflight: int = 2):
+    def __init__(self, window: int, device, group=None, max_inflight: int = 2, max_pending: int = 0):
         if window < 1:
             raise ValueError("window must be >= 1")
         self.window, self.group, self.max_inflight = int(window), group, max(1, int(max_inflight))
+        self.max_pending, self.dropped = int(max_pending), 0   # 0 = keep every reduced window until results() is called
         self._bufs = [torch.zeros(self.window, dtype=torch.float32, device=device) for _ in range(self.max_inflight + 1)]
         self._cur, self._fill = 0, 0
         self._inflight: list[tuple[int, int, object]] = []   # (buffer index, entries, work handle)
@@ -146,6 +147,13 @@ class WindowedEnergyAllReduce:
         if work is not None:
             work.wait()                                   # (stream-side for RCCL: the host does not block)
         self._done.append(self._bufs[b][:cnt].clone())
+        if self.max_pending > 0 and len(self._done) > self.max_pending:
+            if self.dropped == 0:
+                import warnings
+                warnings.warn(f"WindowedEnergyAllReduce: more than {self.max_pending} reduced windows waiting for results(); "
+                              "dropping the oldest (call reduced_energies() / results() from the training loop, or use exchange='step')")
+            self.dropped += len(self._done) - self.max_pending
+            del self._done[:len(self._done) - self.max_pending]
 
     def flush(self) -> None:
         """All-reduce what the current window holds (also called by ``push`` when a window is full)."""
@@ -175,15 +183,18 @@ class WindowedEnergyAllReduce:
 
 
 class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
-    """``SmoothnessBarrierEnergy`` over this rank's spheres + the scalar all-reduce.
+    """``SmoothnessBarrierEnergy`` over this rank's spheres; ``forward`` returns the JOB-WIDE energy (one scalar all-reduce per
+    step, ``exchange="step"``, the default) or, as an explicit opt-in, the rank-local one with the reduction batched
+    over steps (``exchange="window"``).
 
     Parameters mirror the reference module (/root/reference/energies/smooth_barrier.py:34-45) plus
     the sphere layout: ``sphere_vertex_offsets`` / ``sphere_tet_offsets`` (``S+1`` entries each,
     as produced by the multi-sphere geometry's ``base_vid`` bookkeeping).  ``forward`` takes the
     rank-local slice ``x[v_lo:v_hi]`` (use :attr:`vertex_range`); its gradient w.r.t. the local slice is the
-    local gradient.  How the scalar energies of the ranks meet is ``exchange`` (see :meth:`forward`): windowed and
-    asynchronous by default -- at 8-way strong scaling a step is ~70 us and enqueueing a collective per step costs the
-    host about as much -- or one all-reduce per step for code that needs the job-wide value in the loss tensor itself.
+    local gradient.  How the scalar energies of the ranks meet is ``exchange`` (see :meth:`forward`): one all-reduce per
+    step by default -- the returned tensor is then what the reference's module returns, whoever calls it and however
+    often -- or, opted into by a training loop that calls ``forward`` once per step on EVERY rank, windowed and
+    asynchronous (at 8-way strong scaling a step is ~70 us and enqueueing a collective per step costs the host about as much).
 
     ``local_factory(rest_local, tets_local, FLAGS)`` builds the rank-local evaluator; it defaults
     to the HIP-backed ``SmoothnessBarrierEnergy`` and exists so the CPU tests can exercise the
@@ -192,12 +203,13 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
 
     def __init__(self, tet_v, tet_f, FLAGS, sphere_vertex_offsets, sphere_tet_offsets, group=None,
                  rank: int | None = None, world_size: int | None = None,
-                 local_factory: Callable | None = None, exchange: str = "window", window: int = 16):
+                 local_factory: Callable | None = None, exchange: str = "step", window: int = 16):
         super().__init__()
         if exchange not in ("window", "step"):
             raise ValueError("exchange must be 'window' (one collective per `window` steps, off the step's path) or "
                              "'step' (one blocking-order all-reduce per step, job-wide value returned at once)")
         self.exchange, self.window = exchange, int(window)
+        self.max_pending = 64                    # reduced windows kept for reduced_energies() (exchange="window")
         self._reducer = None                     # WindowedEnergyAllReduce, created on the first forward (needs the device)
         initialised = dist.is_available() and dist.is_initialized()
         self.group = group
@@ -235,11 +247,16 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         return self.forward(slice_replicated(x_full, self.vertex_ranges, self.rank, self.group), it, c1, c2)
 
     def forward(self, x_local: torch.Tensor, it, c1, c2):
-        """``exchange="window"`` (default): returns THIS RANK's energy -- its gradient is the rank-local gradient, which is
-        all an optimiser needs -- and files it into a :class:`WindowedEnergyAllReduce`: one asynchronous collective per
-        ``window`` steps, nothing on the step's critical path; :meth:`reduced_energies` hands out the job-wide energies of
-        the steps evaluated so far (what the reference only logs, trainer.py:118-125).
-        ``exchange="step"``: one all-reduce per step, the JOB-WIDE energy is the returned value (same gradient)."""
+        """``exchange="step"`` (default): one all-reduce per call, the JOB-WIDE energy is the returned value; its gradient is
+        the rank-local gradient.  Every rank must make the call (it is a collective).
+        ``exchange="window"`` (opt-in): returns THIS RANK's energy -- same gradient, which is all an optimiser needs --
+        and files it into a :class:`WindowedEnergyAllReduce`: one asynchronous collective per ``window`` steps, nothing on
+        the step's critical path; :meth:`reduced_energies` hands out the job-wide energies of the steps evaluated so far
+        (what the reference only logs, trainer.py:118-125).  Calls under ``torch.no_grad()`` (logging, validation) are NOT
+        filed -- they return the local value and leave the hidden collective state alone, so a rank-0-only log line
+        cannot put the windows of the ranks out of step; at most ``max_pending`` reduced windows are kept for
+        :meth:`reduced_energies` (the oldest are dropped with a warning: a loop that never asks for them does not
+        accumulate device tensors)."""
         if self.local is not None:
             e_local = self.local(x_local, it, c1, c2)
         else:                                   # more ranks than spheres: contribute zero
@@ -247,8 +264,10 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         if self.exchange == "step":
             e_global = all_reduce_energy(e_local, self.group)
             return _AddGlobal.apply(e_local, e_global)
+        if not torch.is_grad_enabled():
+            return e_local
         if self._reducer is None:
-            self._reducer = WindowedEnergyAllReduce(self.window, e_local.device, self.group)
+            self._reducer = WindowedEnergyAllReduce(self.window, e_local.device, self.group, max_pending=self.max_pending)
         self._reducer.push(e_local)
         return e_local
 
