@@ -604,7 +604,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         }
         // the vertex blocks of this wave in the per-vertex sum: 64 consecutive tile vertices each; waves 4-7 take their four
         // blocks in reverse so that every SIMD (waves w, w + 4, w + 8) gets one long and one short block of the sorted vertices
-        const int vb0 = (wave & 4) ? (wave ^ 3) : wave;
+        int vb0 = wave;
+        if (wave & 4) {   // (a permutation of the group's waves whatever the block size: the last group may hold fewer than four)
+            const int g4 = wave & ~3, top = g4 + 3 < nw - 1 ? g4 + 3 : nw - 1;
+            vb0 = g4 + (top - wave);
+        }
         int32_t dst_row = 0;  // where this lane's first vertex goes: fetched here, a whole phase ahead of its use
         if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];
         __syncthreads();   // all waves done with H and with the staged positions
