@@ -299,7 +299,12 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;
     const TileDesc td = a.tiles[tile];
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const float k_c1 = a.coef ? as_global(a.coef)[0] : a.c1, k_c2 = a.coef ? as_global(a.coef)[1] : a.c2;
+    // Device-side scalars -- the coefficients of a graph replay, autograd's grad_output -- are read through the constant address
+    // space: scalar loads that come back with the tile descriptor, not vector loads the head (or, for grad_output, the very end)
+    // of the tile would wait for.
+    typedef const __attribute__((address_space(4))) float *ConstF;
+    const float k_c1 = a.coef ? ((ConstF)(uintptr_t)a.coef)[0] : a.c1, k_c2 = a.coef ? ((ConstF)(uintptr_t)a.coef)[1] : a.c2;
+    const float grad_out_scale = WITH_GRAD && a.grad_out ? *(ConstF)(uintptr_t)a.grad_out : 1.f;
     const auto g_blob = as_global(a.blob);
     const auto g_gvid = as_global(a.gvid);
     const auto g_vdst = as_global(a.vdst);
@@ -371,8 +376,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
 #pragma unroll
         for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
     }
+    // row table: start of row `tid` of the force array, in 12-byte entries.  An unconditional load, like the planes: behind the
+    // join of a divergent branch the compiler waits for EVERY load in flight, and pass 1 would start behind the neighbour planes
+    // (it did, for the first build of this layout: aveg x 952 0.4430 -> 0.4259 ms once the branch was gone).
     uint32_t row0 = 0;
-    if (WITH_GRAD && tid < 72) row0 = g_rowtab[tid < 65 ? tid : 64];   // row table: start of row `tid` of the force array, in 12-byte entries
+    if (WITH_GRAD) row0 = g_rowtab[tid < 65 ? tid : 64];
     __builtin_amdgcn_sched_barrier(0);
 
     // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
@@ -633,10 +641,10 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         // Lane r of every wave holds row r's start address and width: the row loop is wave-uniform (v_readlane), its trip
         // count the slot count of the wave's first -- fullest -- vertex.  Exclusive vertices go straight to grad, vertices
         // shared with other tiles to the staging rows, which the finish kernel sums in plan order.
-        const float gscale = (a.grad_out ? *as_global(a.grad_out) : 1.f) * out_scale;
+        const float gscale = grad_out_scale * out_scale;
         const uint32_t tab = *lds_at<const uint32_t>(4u * uint32_t(lane));
         const uint32_t wid = *lds_at<const uint32_t>(4u * uint32_t(lane) + 4u) - tab;   // 12 * (vertices in row `lane`)
-        for (int vb = vb0; 64 * vb < td.n_verts; vb += nw) {
+        auto vertex_sums = [&](int vb, int32_t row) {
             const int v = 64 * vb + lane;
             const uint32_t v12 = 12u * uint32_t(v);
             const int rows = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wid > 768u * uint32_t(vb)));
@@ -659,7 +667,6 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
                 }
             }
             if (v < td.n_verts) {
-                const int32_t row = vb == vb0 ? dst_row : g_vdst[td.vert_off + v];
                 const bool excl = row >= 0;
                 GLOBAL_AS float *dst = (excl ? g_grad : g_stage) + size_t(excl ? row : ~row) * 3;
                 const float sc = excl ? gscale : out_scale;
@@ -668,6 +675,12 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
                 dst[1] = gy * sc;
                 dst[2] = gz * sc;
             }
+        };
+        if (64 * vb0 < td.n_verts) vertex_sums(vb0, dst_row);
+        if (64 * nw < td.n_verts) {   // more vertices than lanes (rare; a wave-uniform branch: the loads of the extra rounds and the
+                                      // waits the compiler puts around a loop with loads stay out of the common path)
+            for (int vb = vb0 + nw; 64 * vb < td.n_verts; vb += nw)
+                vertex_sums(vb, 64 * vb + lane < td.n_verts ? g_vdst[td.vert_off + 64 * vb + lane] : 0);
         }
     }
 #undef t_own
