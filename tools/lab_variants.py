@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Laboratory builds of the tile kernel WITHOUT touching the product source: every variant is a list of textual patches applied
+to a COPY of tssplat_amd/csrc/kernels.hip (and, optionally, plan.cpp), compiled into tssplat_amd/libtssplat_amd_<name>.so next to
+the product library and selected per process with TSSPLAT_AMD_LIB (tools/ab_variants.py does that).  The shipped kernels carry no
+experiment switches; pricing builds ("what does this phase cost?": results WRONG on purpose) and candidate
+changes live here, reproducible from this file.
+
+    python tools/lab_variants.py --list
+    python tools/lab_variants.py nogather nostore ...      # build
+    python tools/ab_variants.py base nogather nostore --spheres 512
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tssplat_amd import _build  # noqa: E402
+
+K = "kernels.hip"
+P = "plan.cpp"
+
+# name -> (description, [(file, old, new), ...])
+VARIANTS = {
+    # ---- pricing builds: one stage removed, results wrong, cost right ----
+    "exit_p1": ("leave after pass 1 (stream + F): what the memory phase costs", [
+        (K, "    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----",
+            "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----")]),
+    "noscatter": ("no scatter of the corner forces (table reads and address arithmetic stay)", [
+        (K, "                if (p * nq + tid < td.n_slots) {   // (padding slots", "                if (p * nq + tid < td.n_slots && D[p][0] == 12345.678f) {   // (padding slots")]),
+    "nogather": ("per-vertex sums skipped (stores of zeros stay)", [
+        (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];", "            for (int r = 0; r < rows && gscale == 12345.678f; r += 4) {\n                const LDS_AS float *f[4];")]),
+    "nostore": ("result stores skipped", [
+        (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            if (v < td.n_verts && gx == 12345.678f) {\n                const bool excl = row >= 0;")]),
+    "notail": ("no scatter, no sums, no stores: everything behind pass 3", [
+        (K, "                if (p * nq + tid < td.n_slots) {   // (padding slots", "                if (p * nq + tid < td.n_slots && D[p][0] == 12345.678f) {   // (padding slots"),
+        (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];", "            for (int r = 0; r < rows && gscale == 12345.678f; r += 4) {\n                const LDS_AS float *f[4];"),
+        (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            if (v < td.n_verts && gx == 12345.678f) {\n                const bool excl = row >= 0;")]),
+    # ---- candidates ----
+    "nofence": ("no scheduling fence between a lane's slots", [
+        (K, "#define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)", "#define SLOT_FENCE() ((void)0)")]),
+    "nokeeph": ("own H re-read from LDS in pass 3 (18 VGPRs less across the barrier)", [
+        (K, "constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;", "constexpr int kKeepF = SPT, kKeepH = 0;")]),
+    "undef": ("arrays of inactive lanes left opaque-undefined instead of zero-filled (no v_mov per tile)", [
+        (K, "        for (int c = 0; c < 9; ++c) Fk[p][c] = 0.f;\n    if (active) {", "        for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(Fk[p][c]));\n    if (active) {"),
+        (K, "    } else {\n#pragma unroll\n        for (int p = 0; p < SPT; ++p)\n#pragma unroll\n            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;\n    }",
+            "    } else {\n#pragma unroll\n        for (int p = 0; p < SPT; ++p)\n#pragma unroll\n            for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(H[p][c]));\n    }"),
+        (K, "                for (int c = 0; c < 9; ++c) D[p][c] = 0.f;", "                for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(D[p][c]));")]),
+    "keepf3": ("own F kept in registers through pass 3 (own H re-read from LDS): an inverted tet's F is not rebuilt", [
+        (K, "constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;", "constexpr int kKeepF = SPT, kKeepH = 0;"),
+        (K, "                    const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];\n                    float F[9], C[9];\n                    slot_F(kXS, pos_lo(w0), pos_hi(w0), pos_lo(w1), pos_hi(w1), dm, p, F);\n                    cof3(F, C);",
+            "                    float C[9];\n                    cof3(Fk[p], C);")]),
+    "keepf3u": ("keepf3 + undef", []),
+    "b96": ("12-byte LDS accesses of the force array as ONE instruction each (ds_write_b96 / ds_read_b96)", [
+        (K, "                    f0[0] = -(d[0] + d[3] + d[6]), f0[1] = -(d[1] + d[4] + d[7]), f0[2] = -(d[2] + d[5] + d[8]);\n                    f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];\n                    f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];\n                    f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];",
+            "                    typedef float v3f __attribute__((ext_vector_type(3)));\n                    const v3f q0 = {-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8])}, q1 = {d[0], d[1], d[2]}, q2 = {d[3], d[4], d[5]}, q3 = {d[6], d[7], d[8]};\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][0]), \"v\"(q0) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][1]), \"v\"(q1) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][2]), \"v\"(q2) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][3]), \"v\"(q3) : \"memory\");\n                    (void)f0; (void)f1; (void)f2; (void)f3;")]),
+    "identblocks": ("vertex blocks of the per-vertex sums in wave order (no reversal of waves 4-7)", [
+        (K, "        if (wave & 4) {   // (a permutation", "        if (false) {   // (a permutation")]),
+}
+
+
+COMBOS = {"keepf3u": ["keepf3", "undef"], "all1": ["keepf3", "undef", "nofence"]}
+VARIANTS["all1"] = ("keepf3 + undef + nofence", [])
+
+
+def build(name: str) -> str:
+    desc, patches = VARIANTS[name]
+    if name in COMBOS:
+        patches = [q for n in COMBOS[name] for q in VARIANTS[n][1]]
+    srcs = {}
+    for f, old, new in patches:
+        if f not in srcs:
+            srcs[f] = open(os.path.join(_build.CSRC, f)).read()
+        if old not in srcs[f]:
+            raise SystemExit(f"variant {name}: patch anchor not found in {f}: {old[:70]!r}")
+        srcs[f] = srcs[f].replace(old, new)
+    hipcc = _build._hipcc()
+    _build.build()                                      # the product objects of everything that is not patched
+    os.makedirs(_build._OBJ, exist_ok=True)
+    objs = []
+    for src in _build.SOURCES:
+        obj = os.path.join(_build._OBJ, os.path.splitext(src)[0] + ".o")
+        if src in srcs:
+            patched = os.path.join(_build.CSRC, f"_lab_{name}_{src}")      # (next to the original: relative includes resolve)
+            open(patched, "w").write(srcs[src])
+            obj = os.path.join(_build._OBJ, f"{os.path.splitext(src)[0]}_lab_{name}.o")
+            try:
+                if src.endswith(".hip"):
+                    cmd = [hipcc, "-c", patched, "-o", obj] + _build.HOST_FLAGS + _build.DEVICE_FLAGS + _build.SOURCE_FLAGS.get(src, [])
+                else:
+                    cmd = [hipcc] + _build.HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", patched, "-o", obj]
+                subprocess.check_call(cmd)
+            finally:
+                os.remove(patched)
+        objs.append(obj)
+    out = os.path.join(os.path.dirname(_build.LIB), f"libtssplat_amd_{name}.so")
+    subprocess.check_call([hipcc, "-shared", "-o", out] + objs + [f"--offload-arch={_build.ARCH}", "-pthread"])
+    return out
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] == "--list":
+        for k, (d, _) in VARIANTS.items():
+            print(f"{k:14s} {d}")
+        raise SystemExit(0)
+    for n in sys.argv[1:]:
+        print(build(n))

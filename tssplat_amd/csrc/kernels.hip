@@ -34,6 +34,10 @@ constexpr int kWave = 64;
 // Scheduling fence between the slots a lane processes in a pass: one slot's gathers in flight at a time (VGPR budget;
 // letting the compiler interleave them measured +0.1 %).
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A register array that only the active lanes of a tile ever read still needs a definition on the inactive lanes' path (an
+// array left undefined on a path is given registers from the kernel entry on).  An empty asm statement "defines" it there at no
+// cost; zero-filling instead cost ~40 v_mov_b32 per wave and tile (tile kernel -1.8 %, profiles/r05_experiments.md).
+#define UNDEF(x) asm volatile("" : "=v"(x))
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 
@@ -261,7 +265,8 @@ struct KernelArgs {
     float *stage;
     double *partials;
     float c1, c2;
-    const float *coef;  // optional: (c1, c2) read on the device instead (graph replays with changing coefficients)
+    float ratio;        // c2 / c1, divided on the host (set_coefficients): a division costs every wave of every tile a dozen instructions
+    const float *coef;  // optional: (c1, c2) read on the device instead (tsamd_evaluate_dev_coef); the kernel then divides itself
     int order;
     int n_tiles;
     int tiles_per_xcd;
@@ -389,7 +394,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     // Only while c2 / c1 is a well-behaved fp32 number: a tiny c1 would make the ratio overflow (inf * 0 = NaN on every
     // owned, non-inverted tet) or swamp Q's bits.  Outside that range -- and for c1 == 0, which drops Q -- pass 3 applies
     // c1 to Q and c2 to the penalty separately (q_scale) and the vertex sums are written unscaled.
-    const float ratio = k_c2 / k_c1;
+    const float ratio = a.coef ? k_c2 / k_c1 : a.ratio;
     const bool factored = k_c1 != 0.f && __builtin_fabsf(ratio) <= 0x1p+40f;   // (false for inf and NaN as well)
     const float s_pen = factored ? ratio : k_c2, out_scale = factored ? k_c1 : 1.f, q_scale = factored ? 1.f : k_c1;
     // byte address of each own record's ninth entry (see load_slot), once per slot instead of once per access
@@ -418,7 +423,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
 #pragma unroll
     for (int p = 0; p < kKeepF; ++p)
 #pragma unroll
-        for (int c = 0; c < 9; ++c) Fk[p][c] = 0.f;
+        for (int c = 0; c < 9; ++c) UNDEF(Fk[p][c]);
     if (active) {
 #pragma unroll
         for (int p = 0; p < SPT; ++p) {
@@ -499,7 +504,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
 #pragma unroll
         for (int p = 0; p < SPT; ++p)
 #pragma unroll
-            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;
+            for (int c = 0; c < 9; ++c) UNDEF(H[p][c]);
     }
     // ---- the two energy terms are complete: deterministic block reduction (fixed order; doubles across waves) ----
     // Done HERE, around a barrier the tile needs anyway, not at the end of the kernel: there the reduction was a serial
@@ -595,7 +600,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
 #pragma unroll
             for (int p = 0; p < SPT; ++p)
 #pragma unroll
-                for (int c = 0; c < 9; ++c) D[p][c] = 0.f;
+                for (int c = 0; c < 9; ++c) UNDEF(D[p][c]);
         }
         // Where each corner's force goes: row start (LDS byte address, from the table at LDS address 0, indexed by the corner's
         // rank) + 12 * vertex.  The table is read-only from here on, so its reads are issued ahead of the barrier.
@@ -628,7 +633,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
                     const float *d = D[p];
                     LDS_AS float *f0 = lds_at<float>(fdst[p][0]), *f1 = lds_at<float>(fdst[p][1]), *f2 = lds_at<float>(fdst[p][2]),
                                  *f3 = lds_at<float>(fdst[p][3]);
-                    f0[0] = -(d[0] + d[3] + d[6]), f0[1] = -(d[1] + d[4] + d[7]), f0[2] = -(d[2] + d[5] + d[8]);
+                    f0[0] = (-d[0] - d[3]) - d[6], f0[1] = (-d[1] - d[4]) - d[7], f0[2] = (-d[2] - d[5]) - d[8];   // (= -(f1 + f2 + f3), bit for bit)
                     f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];
                     f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];
                     f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];
@@ -1046,6 +1051,13 @@ struct LaunchRecipe {
     size_t tile_lds = 0;
 };
 
+void set_coefficients(KernelArgs &k, float c1, float c2)
+{
+    k.c1 = c1;
+    k.c2 = c2;
+    k.ratio = c2 / c1;   // (IEEE single-precision division, like the kernel's own: inf / NaN for c1 == 0 are handled there)
+}
+
 hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
 {
     if (e.n_tiles > 0) {
@@ -1059,8 +1071,7 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
         k.grad = e.grad;
         k.stage = e.stage;
         k.partials = e.partials;
-        k.c1 = e.c1;
-        k.c2 = e.c2;
+        set_coefficients(k, e.c1, e.c2);
         k.coef = e.coef;
         k.order = e.order;
         k.n_tiles = int(e.n_tiles);
@@ -1184,8 +1195,9 @@ hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t strea
 {
     hipError_t err;
     if (g->r.k.c1 != c1 || g->r.k.c2 != c2 || g->r.f.c1 != c1 || g->r.f.c2 != c2) {
-        g->r.k.c1 = g->r.f.c1 = c1;
-        g->r.k.c2 = g->r.f.c2 = c2;
+        set_coefficients(g->r.k, c1, c2);
+        g->r.f.c1 = c1;
+        g->r.f.c2 = c2;
         if (g->tile_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile_node, &g->tile_p)) != hipSuccess) return err;
         if (g->finish_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish_node, &g->finish_p)) != hipSuccess) return err;
     }
@@ -1309,8 +1321,9 @@ hipError_t train_loop_launch(TrainLoopGraph *g, const TrainLoopStep *steps, floa
         LaunchRecipe &r = g->r[k];
         const TrainLoopStep &s = steps[k];
         if (r.k.c1 != s.c1 || r.k.c2 != s.c2 || r.k.order != s.order || r.f.c1 != s.c1 || r.f.c2 != s.c2) {
-            r.k.c1 = r.f.c1 = s.c1;
-            r.k.c2 = r.f.c2 = s.c2;
+            set_coefficients(r.k, s.c1, s.c2);
+            r.f.c1 = s.c1;
+            r.f.c2 = s.c2;
             r.k.order = s.order;
             if (g->tile[k] && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile[k], &g->tile_p[k])) != hipSuccess) return err;
             if (g->finish[k] && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish[k], &g->finish_p[k])) != hipSuccess) return err;

@@ -905,17 +905,120 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                             std::memcpy(&pl[size_t(4 + 3 * i + k) * size_t(d.s_pad) + s], &v, 4);
                         }
             }
-            // ---- vertex fields: local vertex + the slot's rank at it, handed out in SLOT order (= the order of the per-vertex sum) ----
-            for (int32_t s = 0; s < d.s_pad; ++s) {
-                if (stet[s] < 0) continue;
-                uint32_t lv[4];
-                for (int a = 0; a < 4; ++a) {
-                    int32_t i = S.vert_local[tets[4 * int64_t(stet[s]) + a]];
-                    while (next_rank[size_t(i)] >= tdeg[size_t(i)]) i = copy_of[size_t(i)];   // this copy is full: the hub's next one
-                    lv[a] = uint32_t(i) | (uint32_t(next_rank[size_t(i)]++) << kRankShift);
+            // ---- vertex fields: local vertex + the slot's rank at it ----
+            // Which of its vertex's rows a (slot, corner) writes to is free -- it only fixes the order of the per-vertex sum -- and
+            // decides the LDS bank of the scattered 12-byte entry: entry = row_start[rank] + vertex, bank of its first dword =
+            // 3 * entry mod 32.  The 32 lanes of a half-wave that scatter corner k of their p-th slots in one instruction are
+            // served conflict-free when their entries differ mod 32 (3 is invertible mod 32: the dwords 3e, 3e + 1 of a
+            // ds_write2_b32 then load every bank exactly twice).  Handed out in slot order the entries collide 2.8x as often as
+            // that (kuhn19 and a.veg alike) and the scatter is bound by exactly these conflicts (profiles/r05_experiments.md); so
+            // per half-wave instruction a maximum matching lanes x residues (augmenting paths) picks, for every lane, one of the
+            // still unused ranks of its vertex; a lane left over takes the unused rank whose residue is least loaded.
+            {
+                std::vector<uint16_t> row_start(kMaxRank + 1, 0);     // (the row table proper is written below, from the same degrees)
+                {
+                    int32_t start = 0, width = d.n_verts;
+                    for (int32_t r = 0; r <= kMaxRank; ++r) {
+                        row_start[size_t(r)] = uint16_t(start);
+                        while (width > 0 && tdeg[size_t(width) - 1] <= r) --width;
+                        start += width;
+                    }
                 }
-                pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
-                pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
+                // (slot, corner) -> tile vertex (a hub's copies are filled in slot order), ranks to be chosen
+                std::vector<int32_t> corner_vert(4 * size_t(d.s_pad), -1);
+                std::vector<uint64_t> unused(size_t(d.n_verts), 0);
+                for (int32_t i = 0; i < d.n_verts; ++i) unused[size_t(i)] = tdeg[size_t(i)] >= 64 ? ~uint64_t(0) : ((uint64_t(1) << tdeg[size_t(i)]) - 1);
+                for (int32_t s = 0; s < d.s_pad; ++s) {
+                    if (stet[s] < 0) continue;
+                    for (int a = 0; a < 4; ++a) {
+                        int32_t i = S.vert_local[tets[4 * int64_t(stet[s]) + a]];
+                        while (next_rank[size_t(i)] >= tdeg[size_t(i)]) i = copy_of[size_t(i)];   // this copy is full: the hub's next one
+                        ++next_rank[size_t(i)];
+                        corner_vert[4 * size_t(s) + a] = i;
+                    }
+                }
+                std::vector<uint8_t> corner_rank(4 * size_t(d.s_pad), 0);
+                if (!opt.conflict_aware) {
+                    for (int32_t s = 0; s < d.s_pad; ++s)
+                        for (int a = 0; a < 4; ++a) {
+                            const int32_t i = corner_vert[4 * size_t(s) + a];
+                            if (i < 0) continue;
+                            const int r = __builtin_ctzll(unused[size_t(i)]);
+                            unused[size_t(i)] &= unused[size_t(i)] - 1;
+                            corner_rank[4 * size_t(s) + a] = uint8_t(r);
+                        }
+                } else {
+                    for (int32_t pp = 0; pp < spt; ++pp)
+                        for (int a = 0; a < 4; ++a)
+                            for (int32_t base = 0; base < nq; base += 32) {
+                                int32_t nl = 0, lane_c[32];
+                                for (int32_t tl = base; tl < std::min(base + 32, nq); ++tl) {
+                                    const size_t c = 4 * size_t(spt * tl + pp) + size_t(a);
+                                    if (corner_vert[c] >= 0) lane_c[nl++] = int32_t(c);
+                                }
+                                int32_t owner[32], pick[32];          // residue -> lane, lane -> rank
+                                for (auto &o : owner) o = -1;
+                                for (int32_t l = 0; l < nl; ++l) pick[l] = -1;
+                                auto residue = [&](int32_t l, int r) { return (int32_t(row_start[size_t(r)]) + corner_vert[size_t(lane_c[l])]) & 31; };
+                                struct Matcher {
+                                    int32_t *owner, *pick;
+                                    const int32_t *lane_c;
+                                    const std::vector<int32_t> &corner_vert;
+                                    const std::vector<uint64_t> &unused;
+                                    const std::vector<uint16_t> &row_start;
+                                    bool seen[32];
+                                    bool aug(int32_t l)   // augmenting path from lane l (DFS over at most 32 residues)
+                                    {
+                                        const int32_t v = corner_vert[size_t(lane_c[l])];
+                                        for (uint64_t m = unused[size_t(v)]; m; m &= m - 1) {
+                                            const int r = __builtin_ctzll(m);
+                                            const int32_t res = (int32_t(row_start[size_t(r)]) + v) & 31;
+                                            if (seen[res]) continue;
+                                            seen[res] = true;
+                                            if (owner[res] < 0 || aug(owner[res])) {
+                                                owner[res] = l;
+                                                pick[l] = r;
+                                                return true;
+                                            }
+                                        }
+                                        return false;
+                                    }
+                                } M{owner, pick, lane_c, corner_vert, unused, row_start, {}};
+                                for (int32_t l = 0; l < nl; ++l) {
+                                    std::memset(M.seen, 0, sizeof(M.seen));
+                                    M.aug(l);
+                                }
+                                // (two lanes of the same vertex matched to different residues hold different ranks: same vertex + same
+                                // rank = same residue.)  Commit the matched lanes, then serve the others from what is left.
+                                int32_t load[32] = {};
+                                for (int32_t l = 0; l < nl; ++l)
+                                    if (pick[l] >= 0) {
+                                        unused[size_t(corner_vert[size_t(lane_c[l])])] &= ~(uint64_t(1) << pick[l]);
+                                        ++load[residue(l, pick[l])];
+                                    }
+                                for (int32_t l = 0; l < nl; ++l) {
+                                    if (pick[l] >= 0) continue;
+                                    const int32_t v = corner_vert[size_t(lane_c[l])];
+                                    int best = -1;
+                                    for (uint64_t m = unused[size_t(v)]; m; m &= m - 1) {
+                                        const int r = __builtin_ctzll(m);
+                                        if (best < 0 || load[residue(l, r)] < load[residue(l, best)]) best = r;
+                                    }
+                                    pick[l] = best;
+                                    unused[size_t(v)] &= ~(uint64_t(1) << best);
+                                    ++load[residue(l, best)];
+                                }
+                                for (int32_t l = 0; l < nl; ++l) corner_rank[size_t(lane_c[l])] = uint8_t(pick[l]);
+                            }
+                }
+                for (int32_t s = 0; s < d.s_pad; ++s) {
+                    if (stet[s] < 0) continue;
+                    uint32_t lv[4];
+                    for (int a = 0; a < 4; ++a)
+                        lv[a] = uint32_t(corner_vert[4 * size_t(s) + a]) | (uint32_t(corner_rank[4 * size_t(s) + a]) << kRankShift);
+                    pl[0 * size_t(d.s_pad) + s] = lv[0] | (lv[1] << 16);
+                    pl[1 * size_t(d.s_pad) + s] = lv[2] | (lv[3] << 16);
+                }
             }
             // ---- row table: row r = the vertices met by more than r slots, a prefix of the (sorted) tile vertices ----
             {
