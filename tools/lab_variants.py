@@ -54,12 +54,34 @@ VARIANTS = {
     "b96": ("12-byte LDS accesses of the force array as ONE instruction each (ds_write_b96 / ds_read_b96)", [
         (K, "                    f0[0] = -(d[0] + d[3] + d[6]), f0[1] = -(d[1] + d[4] + d[7]), f0[2] = -(d[2] + d[5] + d[8]);\n                    f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];\n                    f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];\n                    f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];",
             "                    typedef float v3f __attribute__((ext_vector_type(3)));\n                    const v3f q0 = {-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8])}, q1 = {d[0], d[1], d[2]}, q2 = {d[3], d[4], d[5]}, q3 = {d[6], d[7], d[8]};\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][0]), \"v\"(q0) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][1]), \"v\"(q1) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][2]), \"v\"(q2) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][3]), \"v\"(q3) : \"memory\");\n                    (void)f0; (void)f1; (void)f2; (void)f3;")]),
+    "fma4": ("4 * own - first neighbour as one fused multiply-add per entry (5 instructions less per gathered slot and pass)", [
+        (K, """    Mat9 g0 = load_slot(nb[0]);
+    acc.p01 *= 4.f; acc.p23 *= 4.f; acc.p45 *= 4.f; acc.p67 *= 4.f;
+    acc.p8 *= 4.f;
+    Mat9 g1 = load_slot(nb[1]);
+    sub9(acc, g0);""", """    Mat9 g0 = load_slot(nb[0]);
+    Mat9 g1 = load_slot(nb[1]);
+    const v2f four = {4.f, 4.f};
+    acc.p01 = __builtin_elementwise_fma(acc.p01, four, -g0.p01); acc.p23 = __builtin_elementwise_fma(acc.p23, four, -g0.p23);
+    acc.p45 = __builtin_elementwise_fma(acc.p45, four, -g0.p45); acc.p67 = __builtin_elementwise_fma(acc.p67, four, -g0.p67);
+    acc.p8 = __builtin_fmaf(acc.p8, 4.f, -g0.p8);""")]),
+    "sdwa": ("row-table address of a corner in one SDWA instruction ((w >> 8) & 0xfc = byte 1 of the field & 0xfc)", [
+        (K, """            const uint32_t r0 = *lds_at<const uint32_t>((w0 >> 8) & 0xfcu), r1 = *lds_at<const uint32_t>((w0 >> 24) & 0xfcu),
+                           r2 = *lds_at<const uint32_t>((w1 >> 8) & 0xfcu), r3 = *lds_at<const uint32_t>((w1 >> 24) & 0xfcu);""",
+            """            uint32_t ta0, ta1, ta2, ta3;
+            const uint32_t kfc = 0xfcu;
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ta0) : "s"(kfc), "v"(w0));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ta1) : "s"(kfc), "v"(w0));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ta2) : "s"(kfc), "v"(w1));
+            asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ta3) : "s"(kfc), "v"(w1));
+            const uint32_t r0 = *lds_at<const uint32_t>(ta0), r1 = *lds_at<const uint32_t>(ta1), r2 = *lds_at<const uint32_t>(ta2), r3 = *lds_at<const uint32_t>(ta3);""")]),
+    "fs": ("fma4 + sdwa", []),
     "identblocks": ("vertex blocks of the per-vertex sums in wave order (no reversal of waves 4-7)", [
         (K, "        if (wave & 4) {   // (a permutation", "        if (false) {   // (a permutation")]),
 }
 
 
-COMBOS = {"keepf3u": ["keepf3", "undef"], "all1": ["keepf3", "undef", "nofence"]}
+COMBOS = {"keepf3u": ["keepf3", "undef"], "all1": ["keepf3", "undef", "nofence"], "fs": ["fma4", "sdwa"]}
 VARIANTS["all1"] = ("keepf3 + undef + nofence", [])
 
 

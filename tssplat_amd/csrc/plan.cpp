@@ -684,7 +684,9 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 }
                 vcount[size_t(uniq[i])].fetch_add(copies, std::memory_order_relaxed);
             }
-            std::stable_sort(key.begin(), key.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            // (ties by global vertex id: the lanes that gather a tile's positions and store its gradient rows then walk runs of
+            // consecutive rows of x / grad -- fewer memory transactions per wave instruction than in first-touch order)
+            std::sort(key.begin(), key.end());
             auto &tv = tile_verts[size_t(t)];
             auto &td = tile_vdeg[size_t(t)];
             tv.resize(key.size());
