@@ -413,6 +413,37 @@ def test_config4_full_size_properties(ext):
     assert abs(gs.sum(axis=(1, 2)).sum() - gos.sum(axis=(1, 2)).sum()) <= 1e-4 * np.abs(gos).sum() / np.sqrt(go.size)
 
 
+def test_aveg_full_size_properties(ext):
+    """The reference's own mesh class at the headline's size: 952 copies of tssplat_ext/a.veg (TetWild
+    quality, valence <= 56) = 21 058 240 tets.  The same guards as config 4: C-oracle parity at full size (energy guard,
+    gradient L2 guard, per-vertex guard), bit-identical repeats, zero net force / torque per sphere, checksum of checksums."""
+    from tssplat_amd import scenes
+    S = 952
+    sc = scenes.make_scene("aveg", S)
+    assert sc.n_tets == 952 * 22120 and sc.n_vertices == 952 * 4500
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    x = scenes.deform(sc, 0.02)
+    c1, c2 = 2e-4 / S, 2e-4
+    e, g = _eval_gpu(ext, ts, x, c1, c2, 2)
+    e2, g2 = _eval_gpu(ext, ts, x, c1, c2, 2)
+    terms = ts.energy_terms()
+    assert e == e2 and np.array_equal(g, g2), "evaluation must be deterministic (fixed reduction order)"
+    E, go = _assert_guards_c("aveg x952 s=0.02 p=2", sc.rest, sc.tets, x, c1, c2, 2, e, g, nbr=_replicated_adjacency(sc, S), terms=terms)
+    assert abs(e - E) <= 2e-5 * abs(E)
+    assert np.linalg.norm(g - go) <= 5e-4 * np.linalg.norm(go)
+    nv = sc.n_vertices // S
+    gs, gos = g.reshape(S, nv, 3), go.reshape(S, nv, 3)
+    err = np.linalg.norm((gs - gos).reshape(S, -1), axis=1)
+    ref = np.linalg.norm(gos.reshape(S, -1), axis=1)
+    assert np.all(err <= 2e-3 * ref + 1e-12), f"worst sphere: {np.max(err / ref):.2e}"
+    xs = x.astype(np.float64).reshape(S, nv, 3)
+    scale = np.abs(gs).sum(axis=1).max(axis=1)
+    assert np.all(np.abs(gs.sum(axis=1)).max(axis=1) <= 1e-4 * scale)
+    torque = np.cross(xs - xs.mean(axis=1, keepdims=True), gs).sum(axis=1)
+    assert np.all(np.abs(torque).max(axis=1) <= 1e-4 * scale)
+    assert abs(gs.sum(axis=(1, 2)).sum() - gos.sum(axis=(1, 2)).sum()) <= 1e-4 * np.abs(gos).sum() / np.sqrt(go.size)
+
+
 def test_replicated_sphere_beyond_4_gib(ext):
     """64-bit addressing at scale: 1 700 copies of ONE deformed kuhn19 sphere (69.96 M tets, plan planes > 4 GiB, staging rows,
     finish lists and tile blobs addressed far beyond 2^32 bytes).  Every copy is tiled identically (the plan is a function of

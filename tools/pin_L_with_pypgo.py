@@ -153,16 +153,29 @@ def main():
     print(f"libpgo via {how}: n={n} m={m} nnz(GTLTLG)={M_pgo.nnz} nnz(G)={G_pgo.nnz}")
 
     best, best_err, dG = compare(M_pgo, G_pgo, rest, tets)
+    HOW = {"uniform": "nothing to do: it is the operator tsamd_create / TetSpheres(v, f) build in (kernels without weight planes)",
+           "scaled": "TetSpheres(v, f, operator=O.element_laplacian_scaled(O.face_adjacency(tets)))   # O = oracle.tet_energy_oracle; "
+                     "C ABI: the same matrix as CSR (rowptr int64[m+1], col int32, val float64) to tsamd_create_with_operator",
+           "vertex-neighbours": "not expressible: its sparsity exceeds face adjacency (tsamd_create_with_operator rejects it) -- the kernels "
+                                "would need a wider gather; report this"}
     if best_err <= 1e-9:
         Mc, Gc = M_pgo.tocoo(), G_pgo.tocoo()
         np.savez_compressed(args.out, winner=best, mesh=os.path.basename(args.veg), n=n, m=m,
                             M_row=Mc.row.astype(np.int32), M_col=Mc.col.astype(np.int32), M_val=Mc.data,
                             G_row=Gc.row.astype(np.int32), G_col=Gc.col.astype(np.int32), G_val=Gc.data)
         print(f"PINNED: libpgo's operator is the '{best}' candidate (max rel diff {best_err:.1e}); wrote {args.out}\n"
-              "commit that file: tests/test_oracle.py::test_libpgo_pin_if_present checks it from now on")
+              "commit that file: tests/test_oracle.py::test_libpgo_pin_if_present checks it from now on\n"
+              f"operator to pass: {HOW[best]}")
     else:
-        print(f"NO candidate matches (best: {best}, {best_err:.3e}).  The assumption of this repo is wrong for this libpgo; "
-              "use TetSpheres(..., operator=L) / tsamd_create_with_operator with the operator inferred from the dump.")
+        dump = os.path.splitext(args.out)[0] + "_dump.npz"
+        Mc, Gc = M_pgo.tocoo(), G_pgo.tocoo()
+        np.savez_compressed(dump, mesh=os.path.basename(args.veg), n=n, m=m, M_row=Mc.row.astype(np.int32), M_col=Mc.col.astype(np.int32),
+                            M_val=Mc.data, G_row=Gc.row.astype(np.int32), G_col=Gc.col.astype(np.int32), G_val=Gc.data)
+        print(f"NO candidate matches (best: {best}, {best_err:.3e}).  The assumption of this repo is wrong for this libpgo.\n"
+              f"libpgo's matrices are in {dump} (COO: GTLTLG as M_*, G as G_*).  If a global factor made a candidate match above, pass that "
+              "candidate scaled by sqrt(factor); otherwise fit L on the face-adjacency pattern (least squares of (L (x) I9) G against a "
+              "Cholesky-like factor of M) and pass it as TetSpheres(v, f, operator=L) / tsamd_create_with_operator(rowptr, col, val): the "
+              "kernels take ANY operator whose sparsity is diagonal + face adjacency (1.24x the built-in cost when symmetric).")
         sys.exit(2)
 
 
