@@ -76,6 +76,55 @@ VARIANTS = {
             asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ta3) : "s"(kfc), "v"(w1));
             const uint32_t r0 = *lds_at<const uint32_t>(ta0), r1 = *lds_at<const uint32_t>(ta1), r2 = *lds_at<const uint32_t>(ta2), r3 = *lds_at<const uint32_t>(ta3);""")]),
     "fs": ("fma4 + sdwa", []),
+    "prioA": ("wave priority by stage: pass 1 = 0, pass 2 = 1, pass 3 = 2, tail = 3", [
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(1);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(2);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+    ]),
+    "prioB": ("head (load issue) = 3, pass 1 = 0, pass 2 = 1, pass 3 = 2, tail = 3", [
+        (K, '    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n', '    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(1);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(2);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+    ]),
+    "prioC": ("pass 1 = 0, everything behind it = 3", [
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+    ]),
+    "prioD": ("reversed: pass 1 = 3, pass 2 = 2, pass 3 = 1, tail = 0", [
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(2);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(1);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+    ]),
+    "prioE": ("head = 3, pass 1 = 1, pass 2 = 2, pass 3 = 3, tail = 3", [
+        (K, '    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n', '    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(1);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(2);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+    ]),
+    "prioF": ("pass 1 = 0, pass 2 = 0, pass 3 = 2, tail = 3", [
+        (K, '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n', '    // ---- pass 1: F = Ds Dm^-1, inversion penalty ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+        (K, '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n', '    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----\n' + "    " + '__builtin_amdgcn_s_setprio(0);\n'),
+        (K, '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n', '        // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----\n' + "    " + '__builtin_amdgcn_s_setprio(2);\n'),
+        (K, '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n', '        // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----\n' + "    " + '__builtin_amdgcn_s_setprio(3);\n'),
+    ]),
+    "asmpart": ("the tile's energy terms stored by an untracked (inline asm) store: no vmcnt(0) at the join of the lane-0 branch, the last wave does not start pass 3 behind a store acknowledgement", [
+        (K, """            if (lane == 0) {
+                g_partials[2 * size_t(tile)] = s;
+                g_partials[2 * size_t(tile) + 1] = b;
+            }""", """            {
+                const v2u sw = __builtin_bit_cast(v2u, s), bw = __builtin_bit_cast(v2u, b);
+                const v4u val = {uint32_t(__builtin_amdgcn_readlane(int(sw.x), 0)), uint32_t(__builtin_amdgcn_readlane(int(sw.y), 0)),
+                                 uint32_t(__builtin_amdgcn_readlane(int(bw.x), 0)), uint32_t(__builtin_amdgcn_readlane(int(bw.y), 0))};
+                GLOBAL_AS double *dst = g_partials + 2 * size_t(tile);
+                asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(val) : "memory");
+            }""")]),
     "identblocks": ("vertex blocks of the per-vertex sums in wave order (no reversal of waves 4-7)", [
         (K, "        if (wave & 4) {   // (a permutation", "        if (false) {   // (a permutation")]),
 }

@@ -34,6 +34,12 @@ constexpr int kWave = 64;
 // Scheduling fence between the slots a lane processes in a pass: one slot's gathers in flight at a time (VGPR budget;
 // letting the compiler interleave them measured +0.1 %).
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Wave priority by stage: the further a workgroup is through its tile, the higher its waves' issue priority (pass 1: 0 ... the tail: 3).
+// Two workgroups share a CU; the one that is nearer its end frees its LDS sooner when the other -- which is mostly waiting for its
+// stream anyway -- yields the issue slots.  Measured: 512 x kuhn19 -0.6 %, a.veg x 952 -1.4 %; the REVERSE order costs +14 %, and giving
+// the head of a tile (the load issue) top priority costs +8 % (profiles/r05_experiments.md) -- a workgroup in its compute stages must
+// not be disturbed, which is also why workgroups that live for more than one tile lose: they never become the "older" one.
+#define STAGE_PRIORITY(n) __builtin_amdgcn_s_setprio(n)
 // A register array that only the active lanes of a tile ever read still needs a definition on the inactive lanes' path (an
 // array left undefined on a path is given registers from the kernel entry on).  An empty asm statement "defines" it there at no
 // cost; zero-filling instead cost ~40 v_mov_b32 per wave and tile (tile kernel -1.8 %, profiles/r05_experiments.md).
@@ -415,6 +421,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     auto is_owned = [&](int p) { return p * nq + tid < td.n_owned; };
 
     // ---- pass 1: F = Ds Dm^-1, inversion penalty ----
+    STAGE_PRIORITY(0);
     float scal[SPT];  // (c2 / c1) * d(penalty)/d(det F), 0 unless owned and inverted
 #pragma unroll
     for (int p = 0; p < SPT; ++p) scal[p] = 0.f;
@@ -463,6 +470,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     __syncthreads();
 
     // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----
+    STAGE_PRIORITY(1);
     // `owned` is uniform across all but one wave per position: halo slots skip their gathers with a real branch.
     float H[SPT][9];
     auto neighbours = [](uint32_t n01, uint32_t n23, uint32_t *nb) {   // byte addresses of the four records' ninth entries
@@ -553,6 +561,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         sum_waves();
 
         // ---- pass 3: P = L^T H + (c2 / c1) dpen cof(F);  d = P Dm^-T (per-tet vertex forces, c1 applied at the end) ----
+        STAGE_PRIORITY(2);
         // d[k] = P Dminv[k,:]^T is the force on local vertex k+1; vertex 0 gets -(d1+d2+d3).
         // Held in registers across the barrier, then scattered over H (all reads of it done by then).
         float D[SPT][9];
@@ -626,6 +635,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
         if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];
         __syncthreads();   // all waves done with H and with the staged positions
         // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----
+        STAGE_PRIORITY(3);
         if (active) {
 #pragma unroll
             for (int p = 0; p < SPT; ++p) {
