@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Host-side estimate of the tile kernel's LDS bank-conflict cycles, from the plan alone (no GPU).
 
-Replays the addresses of the data-dependent LDS reads (neighbour gathers of passes 2/3, per-vertex force
-gather) through the lane-group / bank rules of MI355X_MICROARCH.md (LDS section) and reports base cycles
-and extra (conflict) cycles per tile slot.  Used to compare ordering heuristics in csrc/plan.cpp offline.
+Replays the addresses of the data-dependent LDS accesses (neighbour gathers of passes 2/3, position reads of pass 1, the
+scatter of the corner forces into the per-vertex force array) through the lane-group / bank rules of MI355X_MICROARCH.md (LDS
+section) and reports base cycles and extra (conflict) cycles per tile slot.  Used to compare ordering heuristics in
+csrc/plan.cpp offline (round 5: the scatter's ranks, 2.8x -> 1.5x the conflict-free cycles).  The per-vertex sums read
+consecutive entries per lane and are conflict-free by construction.
 
     python tools/lds_conflicts.py [--scene kuhn19 --spheres 1] [--no-conflict-aware]
 """
@@ -33,9 +35,17 @@ def tile_conflicts(T, spt, nthr=768):
     sp = T["s_pad"]
     nq = sp // spt
     pl = T["planes"]
-    owned_slot = (pl[0] & 0x8000) != 0
-    nb = (np.stack([pl[2] & 0x7fff, (pl[2] >> 16) & 0x7fff, pl[3] & 0x7fff, (pl[3] >> 16) & 0x7fff], axis=1).astype(np.int64)) // 12
-    res = dict(g128_base=0, g128_extra=0, g32_base=0, g32_extra=0, v_base=0, v_extra=0)
+    slots_all = np.arange(sp)
+    item = (slots_all % spt) * nq + slots_all // spt            # = LDS record index; the items below n_owned are the owned ones
+    owned_slot = item < T["n_owned"]
+    real = T["slot_tet"] >= 0
+    rb = T["rec_base"]
+    nb = (np.stack([pl[2] & 0xffff, pl[2] >> 16, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64) - rb // 4) // 12
+    f16 = np.stack([pl[0] & 0xffff, pl[0] >> 16, pl[1] & 0xffff, pl[1] >> 16], axis=1).astype(np.int64)
+    lv, rank = f16 & 0x3ff, f16 >> 10
+    ent = T["row_start"].astype(np.int64)[rank] + lv
+    res = dict(g128_base=0, g128_extra=0, g32_base=0, g32_extra=0, pos_base=0, pos_extra=0, sc_base=0, sc_extra=0)
+    col0 = (rb // 16) % 16                                       # the record region starts at a 16-byte column of its own
     for p in range(spt):
         for wbase in range(0, nq, 64):
             lanes = np.arange(wbase, min(wbase + 64, nq))
@@ -50,7 +60,7 @@ def tile_conflicts(T, spt, nthr=768):
                         sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) in g and act[i]]
                         if not sel:
                             continue
-                        c = group_cycles((3 * idx[sel]) % 16, idx[sel])
+                        c = group_cycles((3 * idx[sel] + col0) % 16, idx[sel])
                         res["g128_base"] += 2
                         res["g128_extra"] += 2 * (c - 1)
                     for h in range(2):                        # the rotated tail dword
@@ -58,46 +68,29 @@ def tile_conflicts(T, spt, nthr=768):
                         if not sel:
                             continue
                         ii = idx[sel]
-                        bank = (12 * ii + 8 + ((ii >> 3) & 3)) % 32
+                        bank = (rb // 4 + 12 * ii + ((ii >> 3) & 3)) % 32
                         c = group_cycles(bank, ii)
                         res["g32_base"] += 1
                         res["g32_extra"] += c - 1
-    # per-vertex gather (kernels.hip): the first K2 vertices take two lanes each (even / odd chunks), the others one lane
-    inc, off = T["inc"].astype(np.int64), T["inc_off"].astype(np.int64)
-    nv = T["n_verts"]
-    K2 = min(nv, nthr - nv) if nv <= nthr else 0
-    n_lanes = 2 * K2 + (nv - K2)
-    lanes_all = np.arange(n_lanes)
-    v_all = np.where(lanes_all < 2 * K2, lanes_all >> 1, K2 + lanes_all - 2 * K2)
-    h_all = np.where(lanes_all < 2 * K2, lanes_all & 1, 0)
-    st_all = np.where(lanes_all < 2 * K2, 2, 1)
-    pad = (T["s_pad"] << 2) | 1
-    res["v_lb"] = 0
-    for wb in range(0, n_lanes, 64):
-        sl = slice(wb, min(wb + 64, n_lanes))
-        v, h, st = v_all[sl], h_all[sl], st_all[sl]
-        nch = off[v + 1] - off[v]
-        steps = int(np.max((nch - h + st - 1) // st))
-        per_half = [dict(), dict()]
-        for j in range(steps):
-            ch = off[v] + st * j + h
-            ok = ch < off[v + 1]
-            for q in range(4):
-                e = np.where(ok, inc[np.minimum(4 * ch + q, len(inc) - 1)], pad)
-                for half in range(2):
-                    sel = (np.arange(len(v)) // 32) == half
-                    if not sel.any():
+            for k in range(4):
+                # pass 1: one ds_read_b128 of a staged position per corner (16-byte columns: 8 per cycle)
+                for g in G128:
+                    sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) in g and real[slots[i]]]
+                    if sel:
+                        v = lv[slots[sel], k]
+                        res["pos_base"] += 2                  # 16 lanes x 16 bytes over eight 16-byte columns
+                        res["pos_extra"] += max(group_cycles(v % 8, v) - 2, 0)
+                # scatter: ds_write2_b32 (dwords 3e, 3e + 1) + ds_write_b32 (3e + 2) per corner, 32 lanes per cycle group
+                for h in range(2):
+                    sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) // 32 == h and real[slots[i]]]
+                    if not sel:
                         continue
-                    for comp in range(3):
-                        c = group_cycles((3 * e[sel] + comp) % 32, e[sel])
-                        res["v_base"] += 1
-                        res["v_extra"] += c - 1
-                    for x in np.unique(e[sel]):
-                        per_half[half].setdefault(int(x) % 32, set()).add(int(x))
-        # lower bound for this wave: per 32-lane group max(number of read instructions, busiest residue), x 3 components
-        for half in range(2):
-            if per_half[half]:
-                res["v_lb"] += 3 * max(4 * steps, max(len(sx) for sx in per_half[half].values()))
+                    e = ent[slots[sel], k]
+                    b2 = int(np.bincount(np.concatenate([(3 * e) % 32, (3 * e + 1) % 32]), minlength=32).max())
+                    b1 = int(np.bincount((3 * e + 2) % 32, minlength=32).max())
+                    base = -(-2 * len(sel) // 32) + -(-len(sel) // 32)
+                    res["sc_base"] += base
+                    res["sc_extra"] += b2 + b1 - base
     return res
 
 
@@ -123,10 +116,10 @@ def main():
         for k, val in r.items():
             tot[k] = tot.get(k, 0) + val
     print(f"{args.spheres} x {args.scene}: {slots} slots in the first {min(i + 1, args.max_tiles)} tiles; LDS cycles per 64 slots:")
-    for k in ("g128", "g32", "v"):
+    for k, what in (("g128", "neighbour gathers, b128 quads"), ("g32", "neighbour gathers, tail dword"), ("pos", "position reads (pass 1)"),
+                    ("sc", "scatter of the corner forces")):
         b, e = tot[k + "_base"] * 64 / slots, tot[k + "_extra"] * 64 / slots
-        print(f"  {k:5s} base {b:7.1f}  conflict extra {e:7.1f}  ({e / b:.2f}x)")
-    print(f"  v     lower bound of base + extra for the given lane groups: {tot['v_lb'] * 64 / slots:7.1f}")
+        print(f"  {k:5s} base {b:7.1f}  conflict extra {e:7.1f}  ({(b + e) / b:.2f}x)   {what}")
 
 
 if __name__ == "__main__":
