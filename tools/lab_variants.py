@@ -134,6 +134,15 @@ COMBOS = {"keepf3u": ["keepf3", "undef"], "all1": ["keepf3", "undef", "nofence"]
 VARIANTS["all1"] = ("keepf3 + undef + nofence", [])
 
 
+FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> function(list of device flags) -> list
+    "sched_default": lambda f: [x for x in f if x not in ("-mllvm", "-amdgpu-sched-strategy=max-ilp")],
+    "sched_memclause": lambda f: [("-amdgpu-sched-strategy=max-memory-clause" if x == "-amdgpu-sched-strategy=max-ilp" else x) for x in f],
+    "sched_iterilp": lambda f: [("-amdgpu-sched-strategy=iterative-ilp" if x == "-amdgpu-sched-strategy=max-ilp" else x) for x in f],
+}
+for _n in FLAG_VARIANTS:
+    VARIANTS[_n] = (f"compiler flags: {_n}", [(K, "// gfx950 (MI355X / CDNA4) kernels", "// gfx950 (MI355X / CDNA4) kernels")])
+
+
 def build(name: str) -> str:
     desc, patches = VARIANTS[name]
     if name in COMBOS:
@@ -157,7 +166,8 @@ def build(name: str) -> str:
             obj = os.path.join(_build._OBJ, f"{os.path.splitext(src)[0]}_lab_{name}.o")
             try:
                 if src.endswith(".hip"):
-                    cmd = [hipcc, "-c", patched, "-o", obj] + _build.HOST_FLAGS + _build.DEVICE_FLAGS + _build.SOURCE_FLAGS.get(src, [])
+                    dflags = FLAG_VARIANTS[name](list(_build.DEVICE_FLAGS)) if name in FLAG_VARIANTS else _build.DEVICE_FLAGS
+                    cmd = [hipcc, "-c", patched, "-o", obj] + _build.HOST_FLAGS + dflags + _build.SOURCE_FLAGS.get(src, [])
                 else:
                     cmd = [hipcc] + _build.HOST_FLAGS + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", patched, "-o", obj]
                 subprocess.check_call(cmd)
