@@ -138,11 +138,26 @@ def cpu_baseline(args, torch, scenes, sample, x_sample, c1, c2, total_spheres):
         el = time.time() - t0
         if (reps >= 10 and el > 10.0) or el > 25.0:
             break
+    # beside it: what the host can do with the SAME energy matrix-free -- the plain-C float64 oracle (oracle/c, OpenMP over
+    # tets, rest inverses rebuilt per call), all host threads.  Not the reference's formulation; reported so that the GPU / CPU
+    # ratio is not read against torch's sparse kernels alone.
+    from oracle import c_oracle as CO
+    nbr = CO.face_adjacency(sc.tets)
+    CO.energy_and_grad(sc.rest, sc.tets, x_sample, c1, c2, args.order, nbr=nbr)
+    c_reps, t0 = 0, time.time()
+    while True:
+        CO.energy_and_grad(sc.rest, sc.tets, x_sample, c1, c2, args.order, nbr=nbr)
+        c_reps += 1
+        c_el = time.time() - t0
+        if (c_reps >= 5 and c_el > 3.0) or c_el > 8.0:
+            break
     return {
         "value": sc.n_tets * reps / el,
         "unit": "tets/s",
         "cores": int(fixed),
         "kind": "port",
+        "matrix_free_c_oracle": {"value": sc.n_tets * c_reps / c_el, "unit": "tets/s", "cores": int(os.environ.get("OMP_NUM_THREADS", ncpu)),
+                                 "what": f"oracle/c/tet_energy_oracle.c, float64, OpenMP, same sample, {c_reps} fwd+bwd evaluations in {c_el:.1f} s"},
         "cpu_model": _cpu_model(),
         "host_cores": ncpu,
         "sample": f"spheres 0..{sc.n_spheres - 1} of the GPU leg's {total_spheres} x {args.scene} scene (seed 0; same rest mesh, same "
