@@ -12,7 +12,9 @@ What is checked (CPU: there is no GPU here and /root/reference is not on the GPU
     signature of the same-named function of tssplat_amd.dr (names, positional order, keywords such as grad_db=False,
     topology_hash=, pos_gradient_boost=), and this repo's mirror `tssplat_amd.renderers.MeshRasterizer`, driven by the SAME
     reference geometry object, makes the same sequence of calls with the same shapes and returns the same output keys;
-  * `transform_pos` of reference and mirror agree exactly.
+  * `transform_pos` of reference and mirror agree exactly;
+  * VALUES: with a `dr` stand-in that answers every call with oracle/raster_oracle.py's images, the reference's forward and the
+    mirror's return identical tensors (alpha-only and shaded paths, normals, depth) for the same geometry, cameras and material.
 The device-side comparison of the mirrors with the kernels' oracles is tests/test_renderer_pipeline.py / test_raster.py (GPU).
 """
 import importlib
@@ -74,10 +76,31 @@ class _Recorder(types.ModuleType):
         return [(name,) + self._sig(a[1:] if name == "rasterize" else a, k) for name, a, k in self.calls]   # (the context object aside)
 
 
+class _OracleDr(_Recorder):
+    """The same stand-in computing REAL images: every call is answered by oracle/raster_oracle.py (numpy, forward only), so that the
+    reference's forward and the mirror's can be compared on values, not just on the calls they make."""
+
+    def rasterize(self, glctx, pos, tri, resolution, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("rasterize", (glctx, pos, tri, resolution) + args, kwargs))
+        rast = RO.rasterize(pos.detach().numpy(), tri.detach().numpy(), resolution)
+        return torch.from_numpy(rast.astype(np.float32)), torch.zeros(rast.shape, dtype=torch.float32)
+
+    def interpolate(self, attr, rast, tri, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("interpolate", (attr, rast, tri) + args, kwargs))
+        return torch.from_numpy(RO.interpolate(attr.detach().numpy(), rast.detach().numpy(), tri.detach().numpy()).astype(np.float32)), None
+
+    def antialias(self, color, rast, pos, tri, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("antialias", (color, rast, pos, tri) + args, kwargs))
+        return torch.from_numpy(RO.antialias(color.detach().numpy(), rast.detach().numpy(), pos.detach().numpy(), tri.detach().numpy()).astype(np.float32))
+
+
 @pytest.fixture()
-def reference_modules(monkeypatch, tmp_path):
+def reference_modules(monkeypatch, tmp_path, request):
     """The reference's packages importable by their own names, third parties stubbed; everything is undone afterwards."""
-    rec = _Recorder()
+    rec = getattr(request, "param", _Recorder)()
     stubs = {"nvdiffrast": types.ModuleType("nvdiffrast"), "nvdiffrast.torch": rec}
     stubs["nvdiffrast"].torch = rec
     for name in ("cv2", "trimesh", "pymeshlab"):
@@ -186,3 +209,50 @@ def test_reference_rasterizer_calls_bind_to_tssplat_amd_dr_and_match_the_mirror(
     pos = g.tet_v.detach()[g.surface_vid.long()]
     assert torch.equal(ref.transform_pos(mvp, pos), mir.transform_pos(mvp, pos))
     assert torch.equal(ref.transform_pos(mvp, pos, is_vec=True), mir.transform_pos(mvp, pos, is_vec=True))
+
+
+@pytest.mark.parametrize("reference_modules", [_OracleDr], indirect=True)
+def test_reference_forward_and_mirror_render_the_same_images(reference_modules, tmp_path):
+    """Values, not just calls: the reference's `MeshRasterizer.forward` (unmodified) and this repo's mirror, both over a `dr` that
+    answers with the raster oracle's images, return the SAME tensors -- alpha-only and shaded, with normals and depth -- for the same
+    geometry object, cameras, background and material.  (The HIP `dr` against that oracle is tests/test_raster.py on the GPU.)"""
+    geo, ren, rec = reference_modules
+    path, v, t = _veg(tmp_path)
+    g = geo.TetMeshGeometry(_Cfg(use_smooth_barrier=False, initial_mesh_path=path, smooth_barrier_param=None, optimize_geo=True))
+    with torch.no_grad():                                   # a shape with some relief, deterministic
+        g.tet_v.mul_(torch.tensor([1.0, 0.8, 1.15])).add_(0.03 * torch.sin(7.0 * g.tet_v.flip(1)))
+
+    class Flat(torch.nn.Module):                            # stands in for materials.ExplicitMaterial: colour = f(position)
+        def forward(self, positions):
+            return {"color": torch.sigmoid(3.0 * positions)}
+    from tssplat_amd import scenes
+    import tssplat_amd.renderers as mirror_mod
+    mvp = torch.from_numpy(scenes.orbit_mvps(2))
+    campos = torch.tensor([[0.0, 1.0, 3.0], [2.0, 1.0, -2.0]])
+    res = 24
+    bg = torch.rand(2, res, res, 3, generator=torch.Generator().manual_seed(3))
+    ref = ren.MeshRasterizer(g, Flat(), _Cfg(context_type="cuda", is_orhto=False))
+    real_dr = mirror_mod.dr
+    mirror_mod.dr = rec
+    try:
+        mir = mirror_mod.MeshRasterizer(g, Flat(), context_type="cuda", is_orhto=False)
+        for only_alpha in (True, False):
+            kw = dict(only_alpha=only_alpha, iter_num=7, resolution=res, fit_normal=True, fit_depth=True, campos=campos, background=bg)
+            rec.calls.clear()
+            a = ref(mvp, **kw)
+            calls_ref = rec.summary()
+            rec.calls.clear()
+            b = mir(mvp, **kw)
+            assert rec.summary() == calls_ref
+            assert set(a) == set(b)
+            for k in ("shaded", "n", "d"):
+                assert a[k].shape == b[k].shape and torch.equal(a[k].detach(), b[k].detach()), k
+            cover = float((a["shaded"][..., :1] > 0).float().mean()) if only_alpha else None
+            if only_alpha:                                  # the images are not trivial: partly covered, antialiased edge pixels present
+                assert 0.05 < cover < 0.9
+                frac = a["shaded"].detach()
+                assert ((frac > 0.02) & (frac < 0.98)).any()
+            else:
+                assert a["shaded"].shape == (2, res, res, 3) and float(a["n"].abs().max()) > 0.5 and float(a["d"].max()) > 1.0
+    finally:
+        mirror_mod.dr = real_dr
