@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# Some CPU tests import the reference's Python modules from /root/reference (authoring container): the interpreter must not leave
+# bytecode caches in that read-only tree.
+sys.dont_write_bytecode = True
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -24,6 +24,8 @@ import importlib.util
 import os
 import sys
 
+sys.dont_write_bytecode = True        # (nothing is written into /root/reference, not even a bytecode cache)
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -9,6 +9,8 @@ ref_det_golden.npz, so that the pin survives where neither the reference nor the
 import os
 import sys
 
+sys.dont_write_bytecode = True        # (nothing is written into /root/reference, not even a bytecode cache)
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
