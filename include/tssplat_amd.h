@@ -65,10 +65,12 @@ typedef struct tsamd_options {
     int32_t target_owned;      /* owned tets per tile the partitioner aims for; 0 = auto: the fullest tiles that fit, except that a
                                 * plan of <= 1024 tiles built with lds_budget_bytes = max_threads = target_owned = 0 is re-tiled at
                                 * 768 (a small batch pays for a tile's latency, not for its halo) */
-    int32_t reserved0;         /* (0.1: balance_slots.  Owned and halo slots are always interleaved across the lanes now) */
+    int32_t lane_search_sweeps;/* sweeps of the search that seats a tile's tets on the lanes against LDS bank conflicts of the neighbour
+                                * gathers (plan time, ~1.5 ms per tile, sweep and host thread; tile kernel -2 %): 0 = 2, -1 = none
+                                * (tets stay in Morton order).  Results do not depend on it beyond the order of fp32 sums. */
     int32_t host_only;         /* 1 = build the tiling plan only, never touch HIP (CPU tests)       */
     int32_t num_threads;       /* host threads used to build the plan; 0 = hardware concurrency     */
-    int32_t debug_flags;       /* bit1 = no LDS-conflict-aware neighbour ordering (measurements); other bits ignored */
+    int32_t debug_flags;       /* bit1 = no LDS-conflict-aware ordering at all (measurements); other bits ignored */
     int32_t slots_per_thread;  /* tets per lane: 0 = 2.  Lane layouts with a kernel: 2 (max_threads <= 768, two 80 KiB workgroups per
                                 * CU: the default, every operator variant); 3 (max_threads <= 512, or <= 1024 for one workgroup per
                                 * CU) and 4 (max_threads <= 768): fewer, fatter waves, built-in operator only -- with lds_budget_bytes

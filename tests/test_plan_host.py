@@ -220,8 +220,9 @@ from hypothesis import HealthCheck, given, settings, strategies as st  # noqa: E
        spt=st.sampled_from([0, 0, 2, 3, 4]),
        target=st.sampled_from([0, 50, 300, 1000]),
        debug=st.integers(0, 3),
+       lanes=st.sampled_from([0, 0, -1, 1, 4]),
        seed=st.integers(0, 3))
-def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, rebuild, spt, target, debug, seed):
+def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, rebuild, spt, target, debug, lanes, seed):
     from tssplat_amd import tet_spheres_ext as ext
     sc = scenes.make_scene(kind, spheres, seed=seed)
     if spt in (3, 4):
@@ -229,7 +230,7 @@ def test_random_plans_replay_to_oracle(kind, spheres, lds, threads, rebuild, spt
     if spt == 4 and threads == 0:
         pass
     kw = dict(lds_budget_bytes=lds, max_threads=threads, rebuild_dminv=rebuild,
-              target_owned=target, debug_flags=debug, slots_per_thread=spt)
+              target_owned=target, debug_flags=debug, slots_per_thread=spt, lane_search_sweeps=lanes)
     try:
         ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, **kw)
     except RuntimeError as e:      # an infeasible budget must say so, not produce a broken plan
@@ -278,3 +279,55 @@ def test_small_batches_get_smaller_tiles():
         assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()
     big = scenes.make_scene("kuhn8", 400)                      # 1 200 tiles by default: left alone
     assert ext.TetSpheres(big.rest.reshape(-1), big.tets.reshape(-1), host_only=True).plan_info()["n_tiles"] == 1200
+
+
+def _column_overflow(T, spt):
+    """sum((d - 4)^2 over the columns a 16-lane read group meets d > 4 times) of one tile, pass 2 + pass 3 -- what
+    conflict_opt.cpp's lane search minimises, recomputed from the planes alone."""
+    sp, nq, rb = T["s_pad"], T["s_pad"] // spt, T["rec_base"]
+    pl = T["planes"]
+    slot = np.arange(sp)
+    item = (slot % spt) * nq + slot // spt
+    nb = np.empty((sp, 4), np.int64)
+    nb[item] = (np.stack([pl[2] & 0xffff, pl[2] >> 16, pl[3] & 0xffff, pl[3] >> 16], axis=1).astype(np.int64) - rb // 4) // 12
+    lane_group = np.zeros(64, np.int64)
+    for g, lanes in enumerate(([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31])):
+        lane_group[lanes] = g
+        lane_group[[l + 32 for l in lanes]] = g + 2
+    items = np.arange(T["n_slots"])
+    grp = ((items // nq) * (-(-nq // 64)) + (items % nq) // 64) * 4 + lane_group[(items % nq) % 64]
+    total = 0
+    for lim in (T["n_owned"], T["n_slots"]):
+        h = np.zeros((grp.max() + 1, 16), np.int64)
+        np.add.at(h, (np.repeat(grp[:lim], 4), (nb[:lim] % 16).ravel()), 1)
+        total += int((np.clip(h - 4, 0, None) ** 2).sum())
+    return total
+
+
+def test_lane_search_reseats_tets_within_their_tiles_and_lowers_column_overflow():
+    """`lane_search_sweeps`: every tile keeps its owned and its halo tets (only their lanes change), both plans replay to the oracle, and
+    the read-column overflow the search minimises drops by more than a third on a lattice and on an unstructured mesh."""
+    from tssplat_amd import tet_spheres_ext as ext
+    for kind, n in (("kuhn8", 3), ("delaunay1500", 2)):
+        sc = scenes.make_scene(kind, n)
+        plans = [ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, lane_search_sweeps=k) for k in (-1, 0)]
+        spt = plans[0].plan_info()["slots_per_thread"]
+        over = [0, 0]
+        for Ta, Tb in zip(TE.plan_tiles(plans[0]), TE.plan_tiles(plans[1])):
+            assert (Ta["n_slots"], Ta["n_owned"], Ta["s_pad"], Ta["n_verts"]) == (Tb["n_slots"], Tb["n_owned"], Tb["s_pad"], Tb["n_verts"])
+            nq = Ta["s_pad"] // spt
+            slot = np.arange(Ta["s_pad"])
+            item = (slot % spt) * nq + slot // spt
+            for lo, hi in ((0, Ta["n_owned"]), (Ta["n_owned"], Ta["n_slots"])):
+                sel = (item >= lo) & (item < hi)
+                assert np.array_equal(np.sort(Ta["slot_tet"][sel]), np.sort(Tb["slot_tet"][sel]))
+            assert np.array_equal(Ta["gvid"], Tb["gvid"])
+            over[0] += _column_overflow(Ta, spt)
+            over[1] += _column_overflow(Tb, spt)
+        assert over[1] < 0.66 * over[0], (kind, over)
+        cache = O.prepare(sc.rest, sc.tets)
+        x = scenes.deform(sc, 0.2, seed=5)
+        E, _, _, g = O.energy_and_grad(x, cache, 3e-5, 2e-4, 2)
+        for ts in plans:
+            E2, _, _, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 2)
+            assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()

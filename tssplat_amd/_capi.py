@@ -30,7 +30,7 @@ class Options(C.Structure):
         ("lds_budget_bytes", C.c_int32),
         ("max_threads", C.c_int32),
         ("target_owned", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("lane_search_sweeps", C.c_int32),
         ("host_only", C.c_int32),
         ("num_threads", C.c_int32),
         ("debug_flags", C.c_int32),

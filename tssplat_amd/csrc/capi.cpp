@@ -155,6 +155,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     po.target_owned = opt.target_owned;
     po.num_threads = opt.num_threads;
     po.conflict_aware = (opt.debug_flags & 2) ? 0 : 1;  // bit 1 of the debug word switches the LDS-aware neighbour ordering off
+    po.lane_search_sweeps = opt.lane_search_sweeps < 0 ? 0 : (opt.lane_search_sweeps == 0 ? 2 : opt.lane_search_sweeps);
     {
         const int spt = opt.slots_per_thread != 0 ? opt.slots_per_thread : tsamd::kSlotsPerLane;
         if (spt < 2 || spt > 4) return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread must be 0, 2, 3 or 4");

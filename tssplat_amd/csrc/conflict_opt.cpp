@@ -108,4 +108,146 @@ void colour_group_reads(int nl, const uint32_t cand[][4], uint32_t zs, int from[
     }
 }
 
+void search_lane_assignment(int n, int n_owned, int nq, const int32_t *nb, int sweeps, std::vector<int32_t> &item_at)
+{
+    static const uint8_t kGroupOfLane[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,
+                                             2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 2, 2, 3, 3, 3, 3, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3};
+    item_at.resize(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) item_at[size_t(i)] = i;
+    if (n <= 1 || sweeps <= 0) return;
+    const int nwaves = (nq + 63) / 64, npos = (n + nq - 1) / nq;
+    const int ng16 = npos * nwaves * 4;   // 16-lane groups (ds_read_b128); group >> 1 = the half-wave (ds_read_b32 of the ninth dword)
+    std::vector<int32_t> g16(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        const int t = i % nq;
+        g16[size_t(i)] = ((i / nq) * nwaves + (t >> 6)) * 4 + kGroupOfLane[t & 63];
+    }
+    // Who reads item e: an item never leaves its group, so the GROUPS that read e are fixed: per item a short list of
+    // (group, reads by owned items = pass 2 of the kernel, reads by all items = pass 3); at most four neighbours and the item itself.
+    struct Reader {
+        int32_t g;
+        uint8_t n[2];
+    };
+    constexpr int kMaxReaders = 5;
+    std::vector<Reader> readers(size_t(n) * kMaxReaders, Reader{-1, {0, 0}});
+    for (int r = 0; r < n; ++r)
+        for (int k = 0; k < 4; ++k) {
+            Reader *l = &readers[size_t(nb[4 * r + k]) * kMaxReaders];
+            int q = 0;
+            while (q < kMaxReaders - 1 && l[q].g >= 0 && l[q].g != g16[size_t(r)]) ++q;   // (a sixth group cannot occur; it would be merged)
+            l[q].g = g16[size_t(r)];
+            l[q].n[0] = uint8_t(l[q].n[0] + (r < n_owned ? 1 : 0));
+            l[q].n[1] = uint8_t(l[q].n[1] + 1);
+        }
+    // read counts per [group][pass][column]: 16-byte columns within the 16-lane group, banks of the ninth dword within the half-wave
+    std::vector<int16_t> h16(size_t(ng16) * 32, 0), h32(size_t(ng16 / 2) * 64, 0);
+    for (int e = 0; e < n; ++e)
+        for (int q = 0; q < kMaxReaders; ++q) {
+            const Reader &rd = readers[size_t(e) * kMaxReaders + size_t(q)];
+            if (rd.g < 0) break;
+            for (int pas = 0; pas < 2; ++pas) {
+                h16[size_t(rd.g) * 32 + size_t(pas) * 16 + size_t(e & 15)] = int16_t(h16[size_t(rd.g) * 32 + size_t(pas) * 16 + size_t(e & 15)] + rd.n[pas]);
+                h32[size_t(rd.g >> 1) * 64 + size_t(pas) * 32 + size_t(e & 31)] = int16_t(h32[size_t(rd.g >> 1) * 64 + size_t(pas) * 32 + size_t(e & 31)] + rd.n[pas]);
+            }
+        }
+    auto over = [](int d) { return d > 4 ? (d - 4) * (d - 4) : 0; };
+    // Items a (on position pa) and b (on pb) swap: in every group that reads them, the reads of a move from pa's column to pb's and
+    // those of b the other way.  Returns the change of the overflow sum; `commit` also books it.
+    auto swap_cost = [&](int a, int pa, int b, int pb, bool commit) {
+        const Reader *la = &readers[size_t(a) * kMaxReaders], *lb = &readers[size_t(b) * kMaxReaders];
+        int delta = 0;
+        for (int side = 0; side < 2; ++side) {
+            const Reader *l = side ? lb : la, *o = side ? la : lb;
+            for (int q = 0; q < kMaxReaders && l[q].g >= 0; ++q) {
+                int on[2] = {0, 0};            // the other item's reads from the same group
+                bool seen = false;
+                for (int u = 0; u < kMaxReaders && o[u].g >= 0; ++u)
+                    if (o[u].g == l[q].g) on[0] = o[u].n[0], on[1] = o[u].n[1], seen = true;
+                if (side == 1 && seen) continue;   // (handled from a's side)
+                for (int pas = 0; pas < 2; ++pas) {
+                    // net reads that move from pa's column to pb's in this group
+                    const int net = side ? -int(l[q].n[pas]) : int(l[q].n[pas]) - on[pas];
+                    if (net == 0) continue;
+                    int16_t *h = &h16[size_t(l[q].g) * 32 + size_t(pas) * 16];
+                    delta += 2 * (over(h[pa & 15] - net) - over(h[pa & 15]) + over(h[pb & 15] + net) - over(h[pb & 15]));
+                    if (commit) h[pa & 15] = int16_t(h[pa & 15] - net), h[pb & 15] = int16_t(h[pb & 15] + net);
+                }
+            }
+        }
+        // the ninth dword: the same per half-wave.  Two groups of one half-wave may both read an item: their reads are netted per
+        // half-wave before they are priced.
+        int32_t hw[2 * kMaxReaders];
+        int net32[2 * kMaxReaders][2], nh = 0;
+        for (int side = 0; side < 2; ++side) {
+            const Reader *l = side ? lb : la;
+            for (int q = 0; q < kMaxReaders && l[q].g >= 0; ++q) {
+                int u = 0;
+                while (u < nh && hw[u] != (l[q].g >> 1)) ++u;
+                if (u == nh) hw[nh] = l[q].g >> 1, net32[nh][0] = net32[nh][1] = 0, ++nh;
+                for (int pas = 0; pas < 2; ++pas) net32[u][pas] += side ? -int(l[q].n[pas]) : int(l[q].n[pas]);
+            }
+        }
+        for (int u = 0; u < nh; ++u)
+            for (int pas = 0; pas < 2; ++pas) {
+                const int net = net32[u][pas];
+                if (net == 0) continue;
+                int16_t *h = &h32[size_t(hw[u]) * 64 + size_t(pas) * 32];
+                delta += over(h[pa & 31] - net) - over(h[pa & 31]) + over(h[pb & 31] + net) - over(h[pb & 31]);
+                if (commit) h[pa & 31] = int16_t(h[pa & 31] - net), h[pb & 31] = int16_t(h[pb & 31] + net);
+            }
+        return delta;
+    };
+    // The fullest column of the item on position p over the groups that read it, if any of them meets it more than four times: the
+    // histogram row and its modulus.  A swap pays only if it takes an item off such a column and onto a clearly emptier one OF THAT
+    // ROW (a filter, not the decision: the exact price follows).
+    struct Hot {
+        const int16_t *row;
+        int mask;
+    };
+    auto hot = [&](int p) {
+        Hot best{nullptr, 0};
+        int top = 4;
+        const Reader *l = &readers[size_t(item_at[size_t(p)]) * kMaxReaders];
+        for (int q = 0; q < kMaxReaders && l[q].g >= 0; ++q)
+            for (int pas = 0; pas < 2; ++pas) {
+                const int16_t *r16 = &h16[size_t(l[q].g) * 32 + size_t(pas) * 16], *r32 = &h32[size_t(l[q].g >> 1) * 64 + size_t(pas) * 32];
+                if (r16[p & 15] > top) top = r16[p & 15], best = Hot{r16, 15};
+                if (r32[p & 31] > top) top = r32[p & 31], best = Hot{r32, 31};
+            }
+        return best;
+    };
+    // the positions of every group, owned and halo apart (a group's positions never change, the items on them do)
+    std::vector<int32_t> members(static_cast<size_t>(n)), gstart(size_t(ng16) * 2 + 1, 0);
+    for (int i = 0; i < n; ++i) ++gstart[size_t(g16[size_t(i)]) * 2 + (i < n_owned ? 0 : 1) + 1];
+    for (size_t g = 0; g < size_t(ng16) * 2; ++g) gstart[g + 1] += gstart[g];
+    {
+        std::vector<int32_t> fill(gstart.begin(), gstart.end() - 1);
+        for (int i = 0; i < n; ++i) members[size_t(fill[size_t(g16[size_t(i)]) * 2 + (i < n_owned ? 0 : 1)]++)] = i;
+    }
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+        int improved = 0;
+        for (size_t g = 0; g < size_t(ng16) * 2; ++g) {
+            const int32_t *m = members.data() + gstart[g];
+            const int cnt = gstart[g + 1] - gstart[g];
+            Hot hotv[16];   // (refreshed for the two items of an accepted swap only: a stale entry costs a skipped or a wasted trial, no more)
+            for (int i = 0; i < cnt; ++i) hotv[i] = hot(m[i]);
+            for (int ia = 0; ia < cnt; ++ia)
+                for (int ib = ia + 1; ib < cnt; ++ib) {
+                    const int pa = m[ia], pb = m[ib];
+                    const Hot &ha = hotv[ia], &hb = hotv[ib];
+                    if (!((ha.row && ha.row[pb & ha.mask] + 1 < ha.row[pa & ha.mask]) || (hb.row && hb.row[pa & hb.mask] + 1 < hb.row[pb & hb.mask])))
+                        continue;
+                    const int a = item_at[size_t(pa)], b = item_at[size_t(pb)];
+                    if (swap_cost(a, pa, b, pb, false) < 0) {
+                        swap_cost(a, pa, b, pb, true);
+                        item_at[size_t(pa)] = b, item_at[size_t(pb)] = a;
+                        ++improved;
+                        hotv[ia] = hot(pa), hotv[ib] = hot(pb);
+                    }
+                }
+        }
+        if (!improved) break;
+    }
+}
+
 }  // namespace tsamd

@@ -14,4 +14,14 @@ namespace tsamd {
 // unavoidable d - 4 extra cycles on them and nothing else.  from[li][step] = index into cand[li].
 void colour_group_reads(int nl, const uint32_t cand[][4], uint32_t zs, int from[][4]);
 
+// Lane assignment of a tile's items against the same conflicts (round 5; the colouring above then orders each lane's four reads).
+// Item i of a tile is LDS record i and is read by lane (i % nq) of its workgroup at position i / nq; the 16 lanes of a ds_read_b128
+// group hold records of 16 different columns (i mod 16) and every item reads four records (nb[4 * i + k]; its own where a face has no
+// usable neighbour), so a group's 64 reads meet the 16 columns four times each AT BEST: the colouring serves a column read d times
+// in max(d, 4) cycles.  Which item sits on which lane of its group is free.  Local search over swaps of two items of one group
+// (both owned or both halo: items < n_owned stay below n_owned) on the overflow sum((d - 4)^2 over columns with d > 4), counted for
+// pass 2 (owned readers) and pass 3 (all readers), b128 columns (mod 16, per 16-lane group) twice as heavy as the banks of the
+// rotated ninth dword (mod 32, per half-wave).  Deterministic.  item_at[i] = the item that moves to position i.
+void search_lane_assignment(int n, int n_owned, int nq, const int32_t *nb, int sweeps, std::vector<int32_t> &item_at);
+
 }  // namespace tsamd

@@ -799,10 +799,11 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
     parallel_chunks(T, 2, nthreads, [&](int64_t b, int64_t e, int w) {
         Scratch &S = get_scratch(w);
         std::vector<int32_t> next_rank, copy_of;      // per tile vertex: ranks handed out so far; next copy of the same vertex (-1: none)
+        std::vector<int32_t> lane_nb, lane_item_at, lane_tets;
         for (int64_t t = b; t < e; ++t) {
             const TileDesc &d = P.tiles[size_t(t)];
-            const auto &own = tiles_owned[size_t(t)];
-            const auto &halo = tile_halo[size_t(t)];
+            auto &own = tiles_owned[size_t(t)];
+            auto &halo = tile_halo[size_t(t)];
             const auto &tv = tile_verts[size_t(t)];
             const auto &tdeg = tile_vdeg[size_t(t)];
             const int32_t st = S.next();
@@ -828,6 +829,25 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 S.tet_stamp[el] = st + (L < d.n_owned ? 0 : 1);
                 S.tet_slot[el] = slot_of_item(L);
             }
+            // neighbour k of item L as an item (= LDS record) of this tile; a face without a usable neighbour points at the item itself
+            // (halo tets only look at owned neighbours; an owned tet's neighbours are owned or halo by construction)
+            auto neighbour_item = [&](int32_t L, int k) {
+                const int32_t q = P.nbr[4 * size_t(item_tet(L)) + k];
+                if (q >= 0 && (L < d.n_owned || S.tet_stamp[q] == st)) return lds_index(S.tet_slot[q], nq, spt);
+                return L;
+            };
+            if (opt.conflict_aware && opt.lane_search_sweeps > 0) {
+                // ---- which item sits on which lane of its ds_read_b128 group: local search against bank conflicts (conflict_opt.cpp) ----
+                lane_nb.resize(4 * size_t(d.n_slots));
+                for (int32_t L = 0; L < d.n_slots; ++L)
+                    for (int k = 0; k < 4; ++k) lane_nb[4 * size_t(L) + k] = neighbour_item(L, k);
+                search_lane_assignment(d.n_slots, d.n_owned, nq, lane_nb.data(), opt.lane_search_sweeps, lane_item_at);
+                lane_tets.resize(size_t(d.n_slots));
+                for (int32_t L = 0; L < d.n_slots; ++L) lane_tets[size_t(L)] = item_tet(lane_item_at[size_t(L)]);
+                std::copy(lane_tets.begin(), lane_tets.begin() + d.n_owned, own.begin());
+                std::copy(lane_tets.begin() + d.n_owned, lane_tets.end(), halo.begin());
+                for (int32_t L = 0; L < d.n_slots; ++L) S.tet_slot[item_tet(L)] = slot_of_item(L);   // (same tets, same stamps)
+            }
             uint32_t *pl = P.blob.data() + d.blob_off / 4;
             {   // this tile's part of the (uninitialised) plan arrays
                 const uint64_t blob_end = t + 1 < T ? P.tiles[size_t(t) + 1].blob_off : uint64_t(P.blob.size()) * 4;
@@ -844,24 +864,10 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
             for (int32_t L = 0; L < d.n_slots; ++L) {
                 const int32_t el = item_tet(L);
                 const int32_t s = slot_of_item(L);
-                const bool owned = L < d.n_owned;
                 stet[s] = el;
                 uint32_t nb[4];
-                // neighbour k as an LDS record index; a face without a usable neighbour points at the slot itself
-                const uint32_t self = uint32_t(lds_index(s, nq, spt));
-                for (int k = 0; k < 4; ++k) {
-                    int32_t q = P.nbr[4 * size_t(el) + k];
-                    uint32_t v = self;
-                    if (q >= 0) {
-                        int32_t qs = S.tet_stamp[q];
-                        if (owned) {
-                            v = uint32_t(lds_index(S.tet_slot[q], nq, spt));  // by construction q is owned or halo here
-                        } else if (qs == st) {
-                            v = uint32_t(lds_index(S.tet_slot[q], nq, spt));  // halo tets only look at owned neighbours
-                        }
-                    }
-                    nb[k] = v;
-                }
+                const uint32_t self = uint32_t(L);   // (= lds_index(s, nq, spt))
+                for (int k = 0; k < 4; ++k) nb[k] = uint32_t(neighbour_item(L, k));
                 if (weighted) {   // planes 13..21: L[e,e], L[e,n_k], L[n_k,e] in the (not yet re-ordered) neighbour order
                     auto putf = [&](int plane, float v) { std::memcpy(&pl[size_t(plane) * size_t(d.s_pad) + s], &v, 4); };
                     putf(13, P.op_diag[size_t(el)]);

@@ -31,6 +31,7 @@ struct PlanOptions {
     int target_owned = 0;         // 0 = auto
     int num_threads = 0;          // 0 = hardware concurrency
     int conflict_aware = 1;       // order the neighbour entries to dodge LDS bank conflicts
+    int lane_search_sweeps = 2;   // with conflict_aware: sweeps of the lane-assignment search (conflict_opt.cpp), 0 = items stay in Morton order
     int rebuild_dminv = 0;        // 1 = do not stream Dm^-1 (36 of the 52 bytes per slot): keep each tile's REST positions
                                   // (16 B per tile vertex) and invert Dm in registers, in fp32 (see kPlanesRebuild)
     int slots_per_lane = 0;       // 0 = kSlotsPerLane (2); 3 and 4 select the kernels built for fewer, fatter waves

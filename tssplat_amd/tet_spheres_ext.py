@@ -93,7 +93,7 @@ class TetSpheres:
 
     def __init__(self, vertices=None, elements=None, *, device=None, host_only: bool = False,
                  lds_budget_bytes: int = 0, max_threads: int = 0, target_owned: int = 0,
-                 num_threads: int = 0, debug_flags: int = 0,
+                 num_threads: int = 0, debug_flags: int = 0, lane_search_sweeps: int = 0,
                  slots_per_thread: int = 0, operator=None, rebuild_dminv: bool | None = None):
         self._h = C.c_void_p()
         self.n = self.nele = self.n3 = 0
@@ -114,7 +114,7 @@ class TetSpheres:
                                   host_only=int(host_only), lds_budget_bytes=lds_budget_bytes,
                                   max_threads=max_threads, target_owned=target_owned,
                                   num_threads=num_threads,
-                                  debug_flags=int(debug_flags), slots_per_thread=slots_per_thread,
+                                  debug_flags=int(debug_flags), lane_search_sweeps=int(lane_search_sweeps), slots_per_thread=slots_per_thread,
                                   # (the environment default only applies where it can; an explicit True that cannot be
                                   # honoured -- together with operator= -- is rejected by the library, not ignored)
                                   rebuild_dminv=int(REBUILD_DMINV and operator is None) if rebuild_dminv is None
