@@ -108,6 +108,73 @@ void colour_group_reads(int nl, const uint32_t cand[][4], uint32_t zs, int from[
     }
 }
 
+void repair_half_wave_steps(int n, const uint8_t *group, const uint32_t cand[][4], int from[][4])
+{
+    // step q of lane li reads record rid[li][q]
+    uint32_t recs[128];
+    int nrec = 0, rid[32][4];
+    for (int li = 0; li < n; ++li)
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t rec = cand[li][from[li][q]];
+            int r = 0;
+            while (r < nrec && recs[r] != rec) ++r;
+            if (r == nrec) recs[nrec++] = rec;
+            rid[li][q] = r;
+        }
+    // distinct records per step on every 16-byte column of the two ds_read_b128 groups and on every bank of the half-wave's
+    // ds_read_b32; cnt[which][step][record] = lanes that read it there (which: group 0, group 1, half-wave)
+    uint8_t cnt[3][4][128] = {}, load[3][4][32] = {};
+    auto put = [&](int li, int q, int r, int d) {
+        for (int which : {int(group[li]), 2}) {
+            const int col = which == 2 ? int(recs[r] & 31u) : int(recs[r] & 15u);
+            if (d > 0 && cnt[which][q][r]++ == 0) ++load[which][q][col];
+            if (d < 0 && --cnt[which][q][r] == 0) --load[which][q][col];
+        }
+    };
+    for (int li = 0; li < n; ++li)
+        for (int q = 0; q < 4; ++q) put(li, q, rid[li][q], +1);
+    // LDS cycles of step q: two b128 per record and group, one b32 per half-wave
+    auto price = [&](int q) {
+        int t[3] = {0, 0, 0};
+        for (int which = 0; which < 3; ++which)
+            for (int c = 0; c < (which == 2 ? 32 : 16); ++c) t[which] = std::max(t[which], int(load[which][q][c]));
+        return 2 * (t[0] + t[1]) + t[2];
+    };
+    auto squares = [&](int q) {
+        int t = 0;
+        for (int which = 0; which < 3; ++which)
+            for (int c = 0; c < (which == 2 ? 32 : 16); ++c) t += int(load[which][q][c]) * int(load[which][q][c]);
+        return t;
+    };
+    for (int round = 0; round < 6; ++round) {
+        bool better = false;
+        int cost[4];
+        for (int q = 0; q < 4; ++q) cost[q] = price(q);
+        if (cost[0] + cost[1] + cost[2] + cost[3] <= 4 * 5) break;   // conflict-free
+        for (int li = 0; li < n; ++li)
+            for (int q = 0; q < 4; ++q) {
+                const int r1 = rid[li][q];
+                if (load[group[li]][q][recs[r1] & 15u] < 2 && load[2][q][recs[r1] & 31u] < 2) continue;   // this read collides with nothing
+                for (int t = 0; t < 4; ++t) {
+                    if (t == q) continue;
+                    const int r2 = rid[li][t];
+                    const int before = cost[q] + cost[t], sq_before = squares(q) + squares(t);
+                    put(li, q, r1, -1), put(li, t, r2, -1), put(li, t, r1, +1), put(li, q, r2, +1);
+                    const int cq = price(q), ct = price(t);
+                    if (cq + ct < before || (cq + ct == before && squares(q) + squares(t) < sq_before)) {
+                        rid[li][q] = r2, rid[li][t] = r1;
+                        std::swap(from[li][q], from[li][t]);
+                        cost[q] = cq, cost[t] = ct;
+                        better = true;
+                        break;
+                    }
+                    put(li, q, r2, -1), put(li, t, r1, -1), put(li, t, r2, +1), put(li, q, r1, +1);
+                }
+            }
+        if (!better) break;
+    }
+}
+
 void search_lane_assignment(int n, int n_owned, int nq, const int32_t *nb, int sweeps, std::vector<int32_t> &item_at)
 {
     static const uint8_t kGroupOfLane[64] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,

@@ -1061,30 +1061,35 @@ int build_plan(const float *rest, int64_t n, const int32_t *tets, int64_t m, con
                 uint32_t *p2 = pl + 2 * size_t(d.s_pad), *p3 = pl + 3 * size_t(d.s_pad);
                 for (int32_t pp = 0; pp < spt; ++pp)
                     for (int32_t base = 0; base < nq; base += 64)
-                        for (int gi = 0; gi < 4; ++gi) {
-                            int32_t lane_slot[16];
-                            uint32_t cand[16][4];
+                        for (int hw = 0; hw < 2; ++hw) {
+                            int32_t lane_slot[32];
+                            uint32_t cand[32][4];
+                            uint8_t group[32];
+                            int from[32][4];   // step `step` of lane li reads candidate from[li][step] (the weights follow)
                             int nl = 0;
-                            for (int li = 0; li < 16; ++li) {
-                                const int32_t tl = base + kGroups[gi][li];
-                                if (tl >= nq) continue;
-                                const int32_t sl = spt * tl + pp;
-                                lane_slot[nl] = sl;
-                                cand[nl][0] = token_record(p2[sl] & 0xffffu, RB);
-                                cand[nl][1] = token_record(p2[sl] >> 16, RB);
-                                cand[nl][2] = token_record(p3[sl] & 0xffffu, RB);
-                                cand[nl][3] = token_record(p3[sl] >> 16, RB);
-                                ++nl;
+                            for (int gi = 2 * hw; gi < 2 * hw + 2; ++gi) {
+                                const int first = nl;
+                                for (int li = 0; li < 16; ++li) {
+                                    const int32_t tl = base + kGroups[gi][li];
+                                    if (tl >= nq) continue;
+                                    const int32_t sl = spt * tl + pp;
+                                    lane_slot[nl] = sl;
+                                    group[nl] = uint8_t(gi & 1);
+                                    cand[nl][0] = token_record(p2[sl] & 0xffffu, RB);
+                                    cand[nl][1] = token_record(p2[sl] >> 16, RB);
+                                    cand[nl][2] = token_record(p3[sl] & 0xffffu, RB);
+                                    cand[nl][3] = token_record(p3[sl] >> 16, RB);
+                                    ++nl;
+                                }
+                                colour_group_reads(nl - first, cand + first, 0xffffffffu, from + first);   // (no free reads: a missing face reads the slot itself)
                             }
-                            uint32_t chosen[16][4];
-                            int from[16][4];   // chosen[li][step] is candidate from[li][step] (the weights follow)
-                            colour_group_reads(nl, cand, 0xffffffffu, from);   // (no free reads: a missing face reads the slot itself)
-                            for (int li = 0; li < nl; ++li)
-                                for (int step = 0; step < 4; ++step) chosen[li][step] = cand[li][from[li][step]];
+                            repair_half_wave_steps(nl, group, cand, from);
                             for (int li = 0; li < nl; ++li) {
                                 const int32_t sl = lane_slot[li];
-                                p2[sl] = record_token(chosen[li][0], RB) | (record_token(chosen[li][1], RB) << 16);
-                                p3[sl] = record_token(chosen[li][2], RB) | (record_token(chosen[li][3], RB) << 16);
+                                uint32_t chosen[4];
+                                for (int step = 0; step < 4; ++step) chosen[step] = cand[li][from[li][step]];
+                                p2[sl] = record_token(chosen[0], RB) | (record_token(chosen[1], RB) << 16);
+                                p3[sl] = record_token(chosen[2], RB) | (record_token(chosen[3], RB) << 16);
                                 if (weighted)
                                     for (int base_plane : {14, 18}) {
                                         if (base_plane + 4 > n_planes) continue;   // (symmetric operator: no column-weight planes)
