@@ -78,8 +78,8 @@ def tile_conflicts(T, spt, nthr=768):
                     sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) in g and real[slots[i]]]
                     if sel:
                         v = lv[slots[sel], k]
-                        res["pos_base"] += 2                  # 16 lanes x 16 bytes over eight 16-byte columns
-                        res["pos_extra"] += max(group_cycles(v % 8, v) - 2, 0)
+                        res["pos_base"] += 1                  # 16 lanes x 16 bytes over the sixteen 16-byte columns (64 banks)
+                        res["pos_extra"] += group_cycles(v % 16, v) - 1
                 # scatter: ds_write2_b32 (dwords 3e, 3e + 1) + ds_write_b32 (3e + 2) per corner, 32 lanes per cycle group
                 for h in range(2):
                     sel = [i for i in range(len(lanes)) if (lanes[i] - wbase) // 32 == h and real[slots[i]]]
