@@ -37,6 +37,12 @@ VARIANTS = {
         (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];", "            for (int r = 0; r < rows && gscale == 12345.678f; r += 4) {\n                const LDS_AS float *f[4];"),
         (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            if (v < td.n_verts && gx == 12345.678f) {\n                const bool excl = row >= 0;")]),
     # ---- candidates ----
+    "stagger": ("the second workgroup of every CU starts half a tile late (first 512 workgroups: 256-511 sleep ~2.7 us)", [
+        (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
+            "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512)\n        __builtin_amdgcn_s_sleep(100);   // (64 clocks per unit: 6 400 clocks)\n")]),
+    "stagger2": ("same, ~1.3 us", [
+        (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
+            "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512)\n        __builtin_amdgcn_s_sleep(50);\n")]),
     "nofence": ("no scheduling fence between a lane's slots", [
         (K, "#define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)", "#define SLOT_FENCE() ((void)0)")]),
     "nokeeph": ("own H re-read from LDS in pass 3 (18 VGPRs less across the barrier)", [
