@@ -14,7 +14,7 @@ from collections import Counter
 
 def main():
     path = sys.argv[1]
-    want = sys.argv[2] if len(sys.argv) > 2 else "tile_energy_kernelILb1ELi768ELi2ELi6ELb0ELb0E"
+    want = sys.argv[2] if len(sys.argv) > 2 else "tile_energy_kernelILb1ELi768ELi6ELb0ELb0ELi2E"
     lines = open(path).read().split("\n")
     start = next(i for i, ln in enumerate(lines) if ln.startswith("_ZN") and want in ln and ln.rstrip().split(":")[0].endswith("E") and ":" in ln)
     ph = [Counter()]
