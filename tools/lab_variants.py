@@ -40,6 +40,15 @@ VARIANTS = {
     "stagger": ("the second workgroup of every CU starts half a tile late (first 512 workgroups: 256-511 sleep ~2.7 us)", [
         (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
             "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512)\n        __builtin_amdgcn_s_sleep(100);   // (64 clocks per unit: 6 400 clocks)\n")]),
+    "staggerL": ("the workgroup whose LDS allocation does not start at 0 (= the second one of its CU) starts 6 400 clocks late, first 512 workgroups only", [
+        (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
+            "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((11 << 11) | 6) & 0xfff) != 0) __builtin_amdgcn_s_sleep(100);\n")]),
+    "staggerL2": ("same, 3 840 clocks", [
+        (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
+            "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x < 512 && (__builtin_amdgcn_s_getreg((11 << 11) | 6) & 0xfff) != 0) __builtin_amdgcn_s_sleep(60);\n")]),
+    "staggerJ": ("odd workgroups of an XCD among its first 64 start 6 400 clocks late", [
+        (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
+            "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (jb < 64 && (jb & 1)) __builtin_amdgcn_s_sleep(100);\n")]),
     "stagger2": ("same, ~1.3 us", [
         (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
             "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n    if (blockIdx.x >= 256 && blockIdx.x < 512)\n        __builtin_amdgcn_s_sleep(50);\n")]),
