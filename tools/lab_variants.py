@@ -36,6 +36,8 @@ VARIANTS = {
         (K, "                if (p * nq + tid < td.n_slots) {   // (padding slots", "                if (p * nq + tid < td.n_slots && D[p][0] == 12345.678f) {   // (padding slots"),
         (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];", "            for (int r = 0; r < rows && gscale == 12345.678f; r += 4) {\n                const LDS_AS float *f[4];"),
         (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            if (v < td.n_verts && gx == 12345.678f) {\n                const bool excl = row >= 0;")]),
+    "nopen3": ("pricing: the inverted-tet branch of pass 3 (F rebuilt, cofactor) skipped -- what moving it out of stage B could buy at most", [
+        (K, "                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F", "                if (scal[p] == 12345.678f) {  // inverted owned tet: rebuild F")]),
     # ---- candidates ----
     "stagger": ("the second workgroup of every CU starts half a tile late (first 512 workgroups: 256-511 sleep ~2.7 us)", [
         (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
