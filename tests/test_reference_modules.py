@@ -14,7 +14,10 @@ What is checked (CPU: there is no GPU here and /root/reference is not on the GPU
     reference geometry object, makes the same sequence of calls with the same shapes and returns the same output keys;
   * `transform_pos` of reference and mirror agree exactly;
   * VALUES: with a `dr` stand-in that answers every call with oracle/raster_oracle.py's images, the reference's forward and the
-    mirror's return identical tensors (alpha-only and shaded paths, normals, depth) for the same geometry, cameras and material.
+    mirror's return identical tensors (alpha-only and shaded paths, normals, depth) for the same geometry, cameras and material;
+  * the reference's `trainer.train(cfg)` itself runs, unmodified, for a few iterations over this repo's module surface
+    (`pypgo` shim real; `tet_spheres.tet_spheres_ext` and `nvdiffrast.torch` answered by the oracles under this repo's names and
+    signatures): the loss falls, the exports re-load.
 The device-side comparison of the mirrors with the kernels' oracles is tests/test_renderer_pipeline.py / test_raster.py (GPU).
 """
 import importlib
@@ -256,3 +259,186 @@ def test_reference_forward_and_mirror_render_the_same_images(reference_modules, 
                 assert a["shaded"].shape == (2, res, res, 3) and float(a["n"].abs().max()) > 0.5 and float(a["d"].max()) > 1.0
     finally:
         mirror_mod.dr = real_dr
+
+
+class _OracleAutogradDr(_OracleDr):
+    """The oracle-backed stand-in with backward passes (oracle/raster_oracle.py's analytic gradients behind autograd nodes): what the
+    reference's training loop needs to run end to end on the CPU."""
+
+    def rasterize(self, glctx, pos, tri, resolution, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("rasterize", (glctx, pos, tri, resolution) + args, kwargs))
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, pos):
+                rast = torch.from_numpy(RO.rasterize(pos.detach().numpy(), tri.numpy(), resolution).astype(np.float32))
+                ctx.save_for_backward(pos, rast)
+                return rast
+
+            @staticmethod
+            def backward(ctx, g):
+                pos, rast = ctx.saved_tensors
+                return torch.from_numpy(RO.rasterize_backward(pos.numpy(), tri.numpy(), rast.numpy(), g.numpy()).astype(np.float32)).reshape(pos.shape)
+        rast = Fn.apply(pos)
+        return rast, torch.zeros_like(rast)
+
+    def interpolate(self, attr, rast, tri, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("interpolate", (attr, rast, tri) + args, kwargs))
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, attr, rast):
+                ctx.save_for_backward(attr, rast)
+                return torch.from_numpy(RO.interpolate(attr.detach().numpy(), rast.detach().numpy(), tri.numpy()).astype(np.float32))
+
+            @staticmethod
+            def backward(ctx, g):
+                attr, rast = ctx.saved_tensors
+                ga, gr = RO.interpolate_backward(attr.numpy(), rast.numpy(), tri.numpy(), g.numpy())
+                return torch.from_numpy(ga.astype(np.float32)), torch.from_numpy(gr.astype(np.float32))
+        return Fn.apply(attr, rast), None
+
+    def antialias(self, color, rast, pos, tri, *args, **kwargs):
+        from oracle import raster_oracle as RO
+        self.calls.append(("antialias", (color, rast, pos, tri) + args, kwargs))
+        boost = kwargs.get("pos_gradient_boost", 1.0)
+
+        class Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, color, pos):
+                ctx.save_for_backward(color, pos)
+                return torch.from_numpy(RO.antialias(color.detach().numpy(), rast.detach().numpy(), pos.detach().numpy(), tri.numpy()).astype(np.float32))
+
+            @staticmethod
+            def backward(ctx, g):
+                color, pos = ctx.saved_tensors
+                gc, gp = RO.antialias_backward(color.numpy(), rast.detach().numpy(), pos.numpy(), tri.numpy(), g.numpy(), pos_gradient_boost=boost)
+                return torch.from_numpy(gc.astype(np.float32)), torch.from_numpy(gp.astype(np.float32)).reshape(pos.shape)
+        return Fn.apply(color, pos)
+
+
+@pytest.mark.parametrize("reference_modules", [_OracleAutogradDr], indirect=True)
+def test_reference_trainer_runs_unmodified_over_this_repos_module_surface(reference_modules, tmp_path, monkeypatch):
+    """`trainer.train(cfg)` of the reference, UNMODIFIED (trainer.py:35-185), for a few iterations on the CPU: its own
+    `TetMeshMultiSphereGeometry` (pre-computed mesh branch), `SmoothnessBarrierEnergy` + autograd function, `MeshRasterizer`,
+    `AdamUniform`, cosine schedule, exports -- on top of this repo's `pypgo` shim and of stand-ins that answer under THIS repo's
+    module names and signatures: `tet_spheres.tet_spheres_ext` (TetSpheres / forward / backward computed by the oracle, every call
+    also bound to the signature of the same name in tssplat_amd.tet_spheres_ext) and `nvdiffrast.torch` (the raster oracle with its
+    analytic backward, every call bound to tssplat_amd.dr).  The data loader (image files, cv2) and TetWild are replaced by a
+    synthetic batch source / a mesh written here: they are outside the path.  Asserts: the loop runs, the loss it optimises
+    falls, the geometry moves, the exports the trainer writes exist and re-load through the shim."""
+    geo_mod, ren_mod, rec = reference_modules
+    import json
+    from oracle import torch_energies as TE
+    import tssplat_amd.tet_spheres_ext as our_ext
+    import tssplat_amd.dr as our_dr
+    from tssplat_amd import scenes
+
+    # ---- tet_spheres.tet_spheres_ext: the names the reference calls (energies/smooth_barrier.py:6-45), answered by the oracle ----
+    calls = []
+
+    class StandInTetSpheres:
+        def __init__(self, v_flat, f_flat):
+            inspect.signature(our_ext.TetSpheres.__init__).bind(None, v_flat, f_flat)
+            self.ts = TE.TorchTetSpheres(np.asarray(v_flat, np.float32).reshape(-1, 3), np.asarray(f_flat, np.int32).reshape(-1, 4))
+
+    def ext_forward(x, tet_sp, c1, c2, order):
+        inspect.signature(our_ext.forward).bind(x, tet_sp, c1, c2, order)
+        calls.append("forward")
+        return TE.compute_energy(x.detach(), tet_sp.ts, c1, c2, order)
+
+    def ext_backward(grad_output, x, tet_sp, c1, c2, order):
+        inspect.signature(our_ext.backward).bind(grad_output, x, tet_sp, c1, c2, order)
+        calls.append("backward")
+        return TE.compute_energy_backward(grad_output, x.detach(), tet_sp.ts, c1, c2, order)
+    ext = types.ModuleType("tet_spheres.tet_spheres_ext")
+    ext.TetSpheres, ext.forward, ext.backward = StandInTetSpheres, ext_forward, ext_backward
+    pkg = types.ModuleType("tet_spheres")
+    pkg.tet_spheres_ext = ext
+    sb = sys.modules["energies.smooth_barrier"]                  # (already imported by the fixture, against the real shim)
+    monkeypatch.setattr(sb, "tet_spheres_ext", ext)
+
+    # ---- the pre-computed multi-sphere mesh the reference's geometry class loads (tetmesh_geometry.py:221-231) ----
+    sc = scenes.make_scene("kuhn3", 2)
+    mesh_dir = tmp_path / "init"
+    mesh_dir.mkdir()
+    scenes.write_veg(mesh_dir / "final.veg", sc.rest, sc.tets)
+    nv, nt = sc.rest.shape[0] // 2, sc.tets.shape[0] // 2
+    json.dump([list(range(i * nv, (i + 1) * nv)) for i in range(2)], open(mesh_dir / "spheres_vtx_idx.json", "w"))
+    json.dump([sc.tets[i * nt:(i + 1) * nt].tolist() for i in range(2)], open(mesh_dir / "spheres_elem_idx.json", "w"))
+
+    # ---- stubs for what lies outside the path: trimesh's OBJ writer, the data package, materials' loader ----
+    class Trimesh:
+        def __init__(self, vertices=None, faces=None, **kw):
+            self.vertices, self.faces = np.asarray(vertices), np.asarray(faces)
+
+        def export(self, path):
+            with open(path, "w") as f:
+                f.writelines(f"v {a} {b} {c}\n" for a, b, c in self.vertices)
+                f.writelines(f"f {a + 1} {b + 1} {c + 1}\n" for a, b, c in self.faces)
+    monkeypatch.setattr(sys.modules["trimesh"], "Trimesh", Trimesh, raising=False)
+    res, views = 20, 3
+    mvp = torch.from_numpy(scenes.orbit_mvps(views))
+
+    class Loader:
+        num_forward_per_iter = 1
+
+        def __init__(self, cfg):
+            from oracle import raster_oracle as RO
+            # targets: silhouettes of the same two balls, 12 % larger (what the fit must grow into)
+            v, f = sys.modules["geometry.tetrahedron_mesh"].get_surface_vf(sc.tets)
+            pos = np.concatenate([sc.rest[v] * 1.12, np.ones((len(v), 1), np.float32)], 1)
+            clip = np.einsum("vj,bij->bvi", pos, mvp.numpy()).astype(np.float32)
+            rast = RO.rasterize(clip, f, [res, res])
+            alpha = RO.antialias(np.clip(rast[..., 3:], 0, 1), rast, clip, f)
+            self.img = torch.from_numpy(np.concatenate([np.ones((views, res, res, 3)), alpha], -1).astype(np.float32))
+
+        def __call__(self, it, forw_id):
+            return {"img": self.img, "mvp": mvp, "resolution": res, "background": torch.ones(views, res, res, 3),
+                    "campos": torch.zeros(views, 3), "d": torch.zeros(views, res, res, 1), "n": torch.zeros(views, res, res, 3)}
+    data = types.ModuleType("data")
+    data.load_dataloader = lambda kind: Loader
+    monkeypatch.setitem(sys.modules, "data", data)
+    sys.modules["materials"].load_material = lambda kind: None
+    monkeypatch.setattr(sys.modules["utils.config"], "load_config", lambda *a, **k: None, raising=False)
+
+    class Cfg(dict):                                               # the slice of omegaconf.DictConfig the trainer uses
+        __getattr__ = dict.__getitem__
+        __setattr__ = dict.__setitem__
+    out_dir = tmp_path / "results"
+    cfg = Cfg(fitting_stage="geometry", geometry_type="TetMeshMultiSphereGeometry", dataloader_type="X", data=Cfg(), material_type=None,
+              geometry=Cfg(initial_mesh_path=str(mesh_dir), use_smooth_barrier=True,
+                           smooth_barrier_param=Cfg(smooth_eng_coeff=2e-4, barrier_coeff=2e-4, increase_order_iter=1000),   # config/gso.yaml:8-11
+                           template_surface_sphere_path="", key_points_file_path="", tetwild_exec="", tetwild_cache_folder="",
+                           load_precomputed_tetwild_mesh=False, debug_mode=False, optimize_geo=True, output_path=str(out_dir)),
+              renderer=Cfg(context_type="cuda", is_orhto=False),
+              optimizer=Cfg(lr=0.02, grad_limit=True, grad_limit_values=[0.01, 0.01], grad_limit_iters=[1500]),
+              output_path=str(out_dir), total_num_iter=6, use_permute_surface_v=False, verbose=False)
+    monkeypatch.syspath_prepend(REF)
+    for name in ("geometry", "renderers"):                          # `from geometry import load_geometry` etc.: the packages themselves
+        importlib.import_module(name)
+    trainer = importlib.import_module("trainer")
+    try:
+        losses = []
+        monkeypatch.setattr(trainer.tqdm, "write", lambda msg, *a, **k: losses.append(float(msg.split("img_loss=")[1].split(",")[0])))
+        rec.calls.clear()
+        trainer.train(cfg)
+    finally:
+        sys.modules.pop("trainer", None)
+    assert trainer.__file__.startswith(REF)
+    assert len(losses) == 6 and all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert calls.count("forward") == 6 and calls.count("backward") == 6            # the energy, every iteration, both directions
+    names = [c[0] for c in rec.calls]
+    assert names.count("rasterize") == 6 and names.count("antialias") == 6
+    for name, args, kwargs in rec.calls:                          # every renderer call binds to this repo's dr
+        inspect.signature(getattr(our_dr, name)).bind(*args, **kwargs)
+    # what the trainer wrote (trainer.py:141-143, 178): first-iteration and final exports, re-loaded through the pypgo shim
+    import pypgo
+    for sub, stem in (("mesh00000", "00000"), ("final", "final")):
+        m = pypgo.create_tetmesh_from_file(str(out_dir / sub / f"{stem}.veg"))
+        assert np.array_equal(pypgo.get_tetmesh_element_indices(m).reshape(-1, 4), sc.tets)
+    moved = pypgo.get_tetmesh_vertex_positions(m).reshape(-1, 3) - sc.rest
+    assert 1e-4 < np.abs(moved).max() < 0.5
+    assert (out_dir / "final" / "final_vtx.npy").exists() and (out_dir / "final" / "final_sp1_elem.npy").exists()
