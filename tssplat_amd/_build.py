@@ -65,8 +65,8 @@ def traffic_digest() -> str:
 
 
 def build_variant(name: str, extra_device_flags: list[str]) -> str:
-    """Experiment helper: build libtssplat_amd_<name>.so with extra device flags (e.g. -DTSAMD_...).
-    Select it at run time with TSSPLAT_AMD_LIB=<path>."""
+    """Experiment helper: build libtssplat_amd_<name>.so with extra compiler flags (the sources carry no experiment switches:
+    source-level variants are patches of a copy, tools/lab_variants.py).  Select it at run time with TSSPLAT_AMD_LIB=<path>."""
     hipcc = _hipcc()
     out = os.path.join(_HERE, f"libtssplat_amd_{name}.so")
     os.makedirs(_OBJ, exist_ok=True)

@@ -802,33 +802,27 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
     for (int64_t k = int64_t(blockIdx.x - 1) * 256 + tid; k < a.n_finish; k += stride) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
         const int32_t e0 = a.fin_off[k], e1 = a.fin_off[k + 1];   // consecutive rows, tile order
-#ifndef TSAMD_FINISH_ROWS
-#define TSAMD_FINISH_ROWS 4
-#endif
-#ifndef TSAMD_FINISH_SIMPLE
         // the first four rows go out together (most shared vertices have 2-4 copies): one memory latency instead of one
         // per row; rows beyond the vertex's own are re-reads of its last row and are not added.  Finish kernel 0.037 ->
         // 0.031 ms on the 512-sphere scene (2 / 3 / 8 rows: 0.034 / 0.031 / 0.031); same order of additions.
+        constexpr int kRowsAhead = 4;
         {
-            float3 r[TSAMD_FINISH_ROWS];
+            float3 r[kRowsAhead];
 #pragma unroll
-            for (int j = 0; j < TSAMD_FINISH_ROWS; ++j) {
+            for (int j = 0; j < kRowsAhead; ++j) {
                 const int32_t e = e0 + j < e1 ? e0 + j : e1 - 1;
                 const float *p = a.stage + size_t(e) * 3;
                 r[j] = make_float3(p[0], p[1], p[2]);
             }
 #pragma unroll
-            for (int j = 0; j < TSAMD_FINISH_ROWS; ++j)
+            for (int j = 0; j < kRowsAhead; ++j)
                 if (e0 + j < e1) {
                     gx += r[j].x;
                     gy += r[j].y;
                     gz += r[j].z;
                 }
         }
-        for (int32_t e = e0 + TSAMD_FINISH_ROWS; e < e1; ++e) {
-#else
-        for (int32_t e = e0; e < e1; ++e) {
-#endif
+        for (int32_t e = e0 + kRowsAhead; e < e1; ++e) {
             const float *r = a.stage + size_t(e) * 3;
             gx += r[0];
             gy += r[1];

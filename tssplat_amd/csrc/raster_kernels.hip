@@ -126,11 +126,7 @@ __device__ __forceinline__ void drain(WaveQueue &q, int lane)
         for (int j = 0; j < 3; ++j) cur[j] = __hip_atomic_load(slot[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 3   // pricing build: depth reads but no atomics
-            if (key[j] < cur[j] && key[j] == 12345ull) atomicMin(slot[j], key[j]);
-#else
             if (key[j] < cur[j]) atomicMin(slot[j], key[j]);              // (an empty lane's key is all ones: never smaller)
-#endif
     }
     q.count = 0;
 }
@@ -154,14 +150,8 @@ __device__ __forceinline__ void wave_walk(bool mine, int32_t px0, int32_t px1, i
     int32_t px = px0, py = py0;
     Int e0 = r0, e1 = r1, e2 = r2;
     bool active = mine;
-#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 1   // pricing build (tools/ab_raster.py): fetch + set-up only
-    active = false;
-#endif
     while (__ballot(active) != 0ull) {
         bool in = active && (e0 | e1 | e2) >= 0;
-#if defined(TSAMD_BIN_PRICE) && TSAMD_BIN_PRICE == 2   // pricing build: the walk without its fragments
-        in = in && px == -7;
-#endif
         unsigned long long key = 0;
         if (in) {
             // oracle/raster_oracle.py::rasterize_ids, operation by operation (this file is compiled without contraction)
@@ -404,10 +394,7 @@ __global__ __launch_bounds__(256) void rasterize_clip_kernel(const float4 *pos, 
 // A wave holds 64 consecutive pixels of the flattened [view, row, column] image -- what the pair masks are indexed by, and the
 // order in which keys are read and `rast` is written as one stream.  (Four rows x 64 columns per workgroup, the upper neighbour
 // handed over in LDS, was tried: the strided streams alone cost 138 -> 172 us on 120 views x 512^2.)
-#ifndef TSAMD_RESOLVE_PPL
-#define TSAMD_RESOLVE_PPL 4
-#endif
-constexpr int kResolvePixels = TSAMD_RESOLVE_PPL;   // 64-pixel chunks per wave, all their key loads in flight together
+constexpr int kResolvePixels = 4;   // 64-pixel chunks per wave, all their key loads in flight together
 
 __global__ __launch_bounds__(256) void rasterize_resolve_kernel(const float4 *pos, const int32_t *tri, int64_t n_vertices, int64_t batch,
                                                                 int height, int width, const unsigned long long *keys, float4 *rast,
