@@ -150,7 +150,7 @@ def test_config2_64_spheres(ext, sigma, order):
     _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / 64 * mult, 2e-4 * mult, order, label=f"kuhn8x64 s={sigma} p={order}")
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(debug_flags=2), dict(lds_budget_bytes=40960, max_threads=512),
+@pytest.mark.parametrize("kw", [dict(), dict(debug_flags=2), dict(lane_search_sweeps=-1), dict(lane_search_sweeps=4), dict(lds_budget_bytes=40960, max_threads=512),
                                 dict(rebuild_dminv=True), dict(rebuild_dminv=True, max_threads=640, lds_budget_bytes=163840),
                                 dict(max_threads=768, lds_budget_bytes=163840),      # one workgroup per CU
                                 dict(max_threads=384, lds_budget_bytes=40960, target_owned=500)])
@@ -510,7 +510,8 @@ def test_random_tiling_options_on_gpu(ext):
         kw = dict(lds_budget_bytes=int(rng.choice([0, 24000, 40960, 65536, 81920, 120000, 163840])),
                   max_threads=int(rng.choice([0, 128, 256, 512, 640, 768])),
                   rebuild_dminv=bool(rng.integers(4) == 0),
-                  target_owned=int(rng.choice([0, 200, 900])), debug_flags=int(rng.integers(4)))
+                  target_owned=int(rng.choice([0, 200, 900])), debug_flags=int(rng.integers(4)),
+                  lane_search_sweeps=int(rng.choice([0, 0, -1, 1, 3])))
         sc = scenes.make_scene(kind, int(rng.integers(1, 4)), seed=trial)
         try:
             ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), **kw)
