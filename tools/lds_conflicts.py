@@ -100,12 +100,13 @@ def main():
     ap.add_argument("--spheres", type=int, default=1)
     ap.add_argument("--no-conflict-aware", action="store_true")
     ap.add_argument("--max-tiles", type=int, default=12)
+    ap.add_argument("--lane-sweeps", type=int, default=0, help="tsamd_options.lane_search_sweeps (0 = default, -1 = none)")
     args = ap.parse_args()
     from tssplat_amd import scenes, tet_spheres_ext as X
     import tile_emulator as TE
     sc = scenes.make_scene(args.scene, args.spheres)
     ts = X.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True,
-                      debug_flags=2 if args.no_conflict_aware else 0)
+                      debug_flags=2 if args.no_conflict_aware else 0, lane_search_sweeps=args.lane_sweeps)
     spt = ts.plan_info()["slots_per_thread"]
     tot, slots = {}, 0
     for i, T in enumerate(TE.plan_tiles(ts)):
