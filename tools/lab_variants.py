@@ -58,18 +58,12 @@ VARIANTS = {
         (K, "#define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)", "#define SLOT_FENCE() ((void)0)")]),
     "nokeeph": ("own H re-read from LDS in pass 3 (18 VGPRs less across the barrier)", [
         (K, "constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;", "constexpr int kKeepF = SPT, kKeepH = 0;")]),
-    "undef": ("arrays of inactive lanes left opaque-undefined instead of zero-filled (no v_mov per tile)", [
-        (K, "        for (int c = 0; c < 9; ++c) Fk[p][c] = 0.f;\n    if (active) {", "        for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(Fk[p][c]));\n    if (active) {"),
-        (K, "    } else {\n#pragma unroll\n        for (int p = 0; p < SPT; ++p)\n#pragma unroll\n            for (int c = 0; c < 9; ++c) H[p][c] = 0.f;\n    }",
-            "    } else {\n#pragma unroll\n        for (int p = 0; p < SPT; ++p)\n#pragma unroll\n            for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(H[p][c]));\n    }"),
-        (K, "                for (int c = 0; c < 9; ++c) D[p][c] = 0.f;", "                for (int c = 0; c < 9; ++c) asm volatile(\"\" : \"=v\"(D[p][c]));")]),
     "keepf3": ("own F kept in registers through pass 3 (own H re-read from LDS): an inverted tet's F is not rebuilt", [
         (K, "constexpr int kKeepF = SPT, kKeepH = WEIGHTED ? 0 : SPT;", "constexpr int kKeepF = SPT, kKeepH = 0;"),
         (K, "                    const uint32_t w0 = q_lv01[p], w1 = q_lv23[p];\n                    float F[9], C[9];\n                    slot_F(kXS, pos_lo(w0), pos_hi(w0), pos_lo(w1), pos_hi(w1), dm, p, F);\n                    cof3(F, C);",
             "                    float C[9];\n                    cof3(Fk[p], C);")]),
-    "keepf3u": ("keepf3 + undef", []),
     "b96": ("12-byte LDS accesses of the force array as ONE instruction each (ds_write_b96 / ds_read_b96)", [
-        (K, "                    f0[0] = -(d[0] + d[3] + d[6]), f0[1] = -(d[1] + d[4] + d[7]), f0[2] = -(d[2] + d[5] + d[8]);\n                    f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];\n                    f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];\n                    f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];",
+        (K, "                    f0[0] = (-d[0] - d[3]) - d[6], f0[1] = (-d[1] - d[4]) - d[7], f0[2] = (-d[2] - d[5]) - d[8];   // (= -(f1 + f2 + f3), bit for bit)\n                    f1[0] = d[0], f1[1] = d[1], f1[2] = d[2];\n                    f2[0] = d[3], f2[1] = d[4], f2[2] = d[5];\n                    f3[0] = d[6], f3[1] = d[7], f3[2] = d[8];",
             "                    typedef float v3f __attribute__((ext_vector_type(3)));\n                    const v3f q0 = {-(d[0] + d[3] + d[6]), -(d[1] + d[4] + d[7]), -(d[2] + d[5] + d[8])}, q1 = {d[0], d[1], d[2]}, q2 = {d[3], d[4], d[5]}, q3 = {d[6], d[7], d[8]};\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][0]), \"v\"(q0) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][1]), \"v\"(q1) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][2]), \"v\"(q2) : \"memory\");\n                    asm volatile(\"ds_write_b96 %0, %1\" : : \"v\"(fdst[p][3]), \"v\"(q3) : \"memory\");\n                    (void)f0; (void)f1; (void)f2; (void)f3;")]),
     "fma4": ("4 * own - first neighbour as one fused multiply-add per entry (5 instructions less per gathered slot and pass)", [
         (K, """    Mat9 g0 = load_slot(nb[0]);
@@ -147,8 +141,7 @@ VARIANTS = {
 }
 
 
-COMBOS = {"keepf3u": ["keepf3", "undef"], "all1": ["keepf3", "undef", "nofence"], "fs": ["fma4", "sdwa"]}
-VARIANTS["all1"] = ("keepf3 + undef + nofence", [])
+COMBOS = {"fs": ["fma4", "sdwa"]}     # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
 
 
 FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> function(list of device flags) -> list
