@@ -331,3 +331,16 @@ def test_lane_search_reseats_tets_within_their_tiles_and_lowers_column_overflow(
         for ts in plans:
             E2, _, _, g2 = TE.emulate(ts, x, 3e-5, 2e-4, 2)
             assert abs(E - E2) <= 1e-11 * abs(E) and np.abs(g - g2).max() <= 1e-10 * np.abs(g).max()
+
+
+def test_plan_does_not_depend_on_the_number_of_host_threads():
+    """The planner works tile by tile with deterministic searches: one host thread and eight build the same bytes."""
+    from tssplat_amd import tet_spheres_ext as ext
+    sc = scenes.make_scene("delaunay1500", 4)
+    a, b = (ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), host_only=True, num_threads=k) for k in (1, 8))
+    n = 0
+    for Ta, Tb in zip(TE.plan_tiles(a), TE.plan_tiles(b)):
+        for k in ("planes", "gvid", "vdst", "slot_tet", "row_start"):
+            assert np.array_equal(Ta[k], Tb[k]), k
+        n += 1
+    assert n == a.plan_info()["n_tiles"] == b.plan_info()["n_tiles"] > 8
