@@ -16,7 +16,7 @@ for cfg in "kuhn19 512" "aveg 952" "delaunay6000 540" "kuhn8 256" "kuhn8 64"; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_fetch_$W.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_write_$W.log 2>&1
 done
-for cfg in "kuhn19 512" "aveg 952"; do set -- $cfg
+for cfg in "kuhn19 512" "aveg 952" "delaunay6000 540"; do set -- $cfg
   W=$1x$2
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq1_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_sq1_$W.log 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq2_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_sq2_$W.log 2>&1
