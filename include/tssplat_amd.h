@@ -56,7 +56,7 @@ typedef enum tsamd_status {
     TSAMD_ERR_HOST_ONLY = 7          /* device entry point called on a host_only handle            */
 } tsamd_status;
 
-/* Zero-initialise, set struct_size = sizeof(tsamd_options), override what you need. */
+/* Zero-initialise, set struct_size = sizeof(tsamd_options) and abi_version = TSAMD_ABI_VERSION, override what you need. */
 typedef struct tsamd_options {
     int32_t struct_size;
     int32_t device;            /* HIP device ordinal; -1 = current device                          */
@@ -80,6 +80,9 @@ typedef struct tsamd_options {
                                 * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per
                                 * evaluation, entries of Dm^-1 within 2.8e-7 relative of the exact inverse instead of
                                 * 5.9e-8 (double -> fp32 rounding, tet_spheres.cpp:43-45).  Not with an explicit operator. */
+    int32_t abi_version;       /* must be TSAMD_ABI_VERSION of the header the caller was compiled against: ABI 1 and 2 shared one
+                                * struct size while two fields changed their meaning in place, so a stale caller was re-interpreted
+                                * instead of rejected.  From ABI 3 on the size changes with the version AND the version is checked. */
 } tsamd_options;
 
 /* Introspection of the tiling plan (host side; valid for host_only handles too). */
@@ -120,7 +123,7 @@ const char *tsamd_last_error(void);
 const char *tsamd_version(void);
 /* Bumped whenever a struct layout or a signature of this header changes incompatibly (0.1 had no such call: a caller that
  * cannot find the symbol is talking to an older library).  Compare with TSAMD_ABI_VERSION of the header you compiled against. */
-#define TSAMD_ABI_VERSION 2
+#define TSAMD_ABI_VERSION 3
 int32_t tsamd_abi_version(void);
 
 /*

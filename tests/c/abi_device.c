@@ -76,6 +76,7 @@ int main(void)
 
     memset(&opt, 0, sizeof opt);
     opt.struct_size = (int32_t)sizeof opt;
+    opt.abi_version = TSAMD_ABI_VERSION;
     opt.device = 0;
     opt.lds_budget_bytes = 24000; /* several tiles: halo slots, staged vertices and the finish kernel take part */
     if (tsamd_create(rest, NV, tets, NT, &opt, &h) != TSAMD_OK) {

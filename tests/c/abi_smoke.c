@@ -22,6 +22,7 @@ int main(void)
     if (strstr(tsamd_version(), "gfx950") == NULL) return 10;
     memset(&opt, 0, sizeof opt);
     opt.struct_size = (int32_t)sizeof opt;
+    opt.abi_version = TSAMD_ABI_VERSION;
     opt.device = -1;
     opt.host_only = 1; /* plan only: no HIP call is made */
     if (tsamd_create(rest, 5, tets, 2, &opt, &h) != TSAMD_OK) {

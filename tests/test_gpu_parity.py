@@ -89,7 +89,7 @@ def _assert_parity(ext, ts, scene_rest, scene_tets, x_np, c1, c2, order, go=1.0,
     assert ratio_v <= GUARD_V, f"{label}: a vertex is off by {ratio_v:.1f} predicted standard deviations"
     # energy terms individually
     es_gpu, eb_gpu = ts.energy_terms()
-    assert abs(es_gpu - Es) <= tol_e / max(float(np.float32(c1)), 1e-30) + 1e-12
+    assert abs(es_gpu - Es) <= tol_e / max(float(np.float32(c1)), 1e-30) + 1e-12 + 1e-6 * abs(Es)   # (the last term: c1 == c2 == 0 makes tol_e 0)
     assert abs(eb_gpu - Eb) <= 2e-5 * Eb + 1e-12 + tol_e / max(float(np.float32(c2)), 1e-30)
 
 
@@ -523,6 +523,121 @@ def test_random_tiling_options_on_gpu(ext):
                        go=float(rng.choice([1.0, 0.25])), label=f"random#{trial} {kind} {kw}")
         ran += 1
     assert ran >= 10
+
+
+# Every lane layout tile_kernel_for() hands out besides the default (kernels.hip): 3 slots per lane x 512 threads (two workgroups
+# per CU), 3 x 1 024 and 4 x 768 (one workgroup per CU, up to 160 KiB).  VERDICT r5 / ADVICE r5: these six instantiations were
+# only covered by the CPU plan replay.  Device-side differences against the default: plane loads of SPT dwords at a 12- / 16-byte lane
+# stride, 1 024-thread blocks (16 waves in the block reduction), the reversed vertex blocks of waves 4-7 at other wave counts,
+# 128 / 168-VGPR launch bounds.
+_LANE_LAYOUTS = [dict(slots_per_thread=3, max_threads=512), dict(slots_per_thread=3, max_threads=512, lds_budget_bytes=54400),
+                 dict(slots_per_thread=3, max_threads=1024, lds_budget_bytes=163840),
+                 dict(slots_per_thread=4, max_threads=768, lds_budget_bytes=163840),
+                 dict(slots_per_thread=4, max_threads=768), dict(slots_per_thread=3, max_threads=1024)]
+
+
+@pytest.mark.parametrize("kw", _LANE_LAYOUTS, ids=lambda kw: "spt%d_%d_%d" % (kw["slots_per_thread"], kw["max_threads"], kw.get("lds_budget_bytes", 0)))
+@pytest.mark.parametrize("kind,S", [("kuhn19", 3), ("delaunay3000", 3)])
+def test_lane_layouts_multi_tile(ext, kw, kind, S):
+    """slots_per_thread 3 and 4 on multi-tile scenes (halo slots, staged shared vertices, finish kernel): order 2 and 4, fused
+    forward + backward AND the forward-only kernels, against the oracle."""
+    from tssplat_amd import scenes
+    sc = scenes.make_scene(kind, S, seed=5)
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), **kw)
+    info = ts.plan_info()
+    assert info["slots_per_thread"] == kw["slots_per_thread"] and info["n_tiles"] >= S
+    assert info["block_threads"] <= kw["max_threads"] and info["n_planes"] == 13
+    for sigma, order, go in ((0.02, 2, 1.0), (0.3, 4, 0.37)):
+        x = scenes.deform(sc, sigma, seed=11)
+        _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / S, 2e-4, order, go=go, label=f"{kind}x{S} {kw} s={sigma} p={order}")
+        # the forward-only instantiation <false, ...> of the same layout: same energy as the fused pass (fixed-order sums)
+        xt = torch.from_numpy(x).cuda()
+        e_fwd = float(ext.forward(xt, ts, 2e-4 / S, 2e-4, order, fuse=False))
+        e_fused = float(ext.forward(xt.clone().requires_grad_(True), ts, 2e-4 / S, 2e-4, order))
+        assert abs(e_fwd - e_fused) <= 1e-6 * abs(e_fused), (e_fwd, e_fused)
+
+
+@pytest.mark.parametrize("kw", [dict(slots_per_thread=3, max_threads=1024, lds_budget_bytes=163840),
+                                dict(slots_per_thread=4, max_threads=768, lds_budget_bytes=163840)],
+                         ids=["spt3_1024", "spt4_768"])
+def test_lane_layouts_whole_sphere_tiles(ext, kw):
+    """With 160 KiB a 3 072-tet sphere is ONE tile: no halo (slots = tets), no shared vertices, no staging rows -- the finish
+    kernel only reduces the energy partials.  Also the hub-vertex fixture (a vertex split into copies of <= 64 slots INSIDE one
+    tile goes through the staging rows even then)."""
+    from tssplat_amd import scenes
+    sc = scenes.make_scene("kuhn8", 8)
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1), **kw)
+    info = ts.plan_info()
+    assert info["n_tiles"] == 8 and info["total_slots"] == sc.n_tets and info["shared_vertex_copies"] == 0, info
+    for sigma, order in ((0.0, 2), (0.02, 2), (0.3, 4)):
+        x = scenes.deform(sc, sigma)
+        _assert_parity(ext, ts, sc.rest, sc.tets, x, 2e-4 / 8, 2e-4, order, label=f"kuhn8x8 one tile per sphere {kw} s={sigma} p={order}")
+    cone = scenes.make_scene("cone", 3)
+    tc = ext.TetSpheres(cone.rest.reshape(-1), cone.tets.reshape(-1), **kw)
+    _assert_parity(ext, tc, cone.rest, cone.tets, scenes.deform(cone, 0.2), 1e-4, 2e-4, 2, go=0.5, label=f"cone x3 {kw}")
+
+
+@pytest.mark.parametrize("c1,c2", [(0.0, 2e-4), (2e-4, 0.0), (1e-30, 2e-4), (0.0, 0.0)], ids=["c1=0", "c2=0", "c1=1e-30", "both=0"])
+@pytest.mark.parametrize("order", [2, 4])
+def test_unfactored_coefficient_branch_gradient(ext, c1, c2, order):
+    """Pass 3 works with c2 / c1 and applies c1 once per vertex -- except where the ratio is not a well-behaved fp32 number (c1 == 0:
+    only the penalty is left; |c2 / c1| > 2^40; NaN for 0 / 0), where c1 and c2 are applied separately and the vertex sums are written
+    unscaled (kernels.hip: `factored`, q_scale).  VERDICT r5: that branch's GRADIENT was never compared with the oracle.  Multi-tile
+    scene with many inverted tets, both coefficient routes: launch arguments and the device-side coefficient buffer of a graph replay."""
+    from tssplat_amd import scenes
+    sc = scenes.make_scene("kuhn19", 2)
+    ts = ext.TetSpheres(sc.rest.reshape(-1), sc.tets.reshape(-1))
+    assert ts.plan_info()["shared_vertex_copies"] > 0
+    x = scenes.deform(sc, 0.3)
+    O = _oracle()
+    cache = O.prepare(sc.rest, sc.tets)
+    E, Es, Eb, g = O.energy_and_grad(x, cache, c1, c2, order, grad_output=0.6)
+    assert Eb > 0 and Es > 0
+    _assert_parity(ext, ts, sc.rest, sc.tets, x, c1, c2, order, go=0.6, label=f"unfactored c1={c1} c2={c2} p={order}")
+    # the same through the two other coefficient routes: a HIP-graph replay (coefficients = node arguments, ratio divided on the
+    # host) and tsamd_evaluate_dev_coef (coefficients read from a device buffer: the kernel divides c2 / c1 itself)
+    import ctypes as C
+    from tssplat_amd import _capi
+    from tssplat_amd.energies import SmoothnessBarrierEnergy
+    from tssplat_amd.energies.graphed import GraphedSmoothnessBarrier
+
+    class Flags:
+        smooth_eng_coeff, barrier_coeff, increase_order_iter = c1, c2, 1000
+
+    mod = SmoothnessBarrierEnergy(sc.rest, sc.tets, Flags)
+    xt = torch.from_numpy(x).cuda()
+    gr = GraphedSmoothnessBarrier(mod, xt, grad_scale=0.6)
+    e_rep, g_rep = gr.evaluate(c1, c2, order)
+    coef = torch.tensor([c1, c2], dtype=torch.float32, device="cuda")
+    go = torch.tensor([0.6], dtype=torch.float32, device="cuda")
+    e_dev = torch.zeros((), dtype=torch.float32, device="cuda")
+    g_dev = torch.full_like(xt, float("nan"))
+    _capi.check(_capi.load().tsamd_evaluate_dev_coef(mod.tet_sp._handle(), xt.data_ptr(), go.data_ptr(), coef.data_ptr(), order, None,
+                                                     e_dev.data_ptr(), g_dev.data_ptr()))
+    torch.cuda.synchronize()
+    for tag, e_k, g_k in (("replay", e_rep, g_rep), ("dev_coef", e_dev, g_dev)):
+        g_k = g_k.cpu().numpy().astype(np.float64)
+        assert abs(float(e_k) - E) <= 1e-5 * abs(E) + 1e-12, tag
+        assert np.linalg.norm(g_k - g) <= 2e-5 * np.linalg.norm(g) + 1e-12, tag
+        if c1 == 0.0 and c2 == 0.0:
+            assert float(e_k) == 0.0 and not g_k.any(), tag
+
+
+def test_unreferenced_vertices_on_gpu(ext):
+    """Vertices no tet references (the FIRST vertex of the array among them: its finish entry has zero staging rows at offset 0,
+    ADVICE r5) get a zero gradient from the finish kernel; everything else matches the oracle."""
+    from tssplat_amd import scenes
+    sc = scenes.make_scene("kuhn8", 2)
+    pad = np.array([[9.0, 9.0, 9.0]], np.float32)
+    rest = np.concatenate([pad, sc.rest, pad, pad]).astype(np.float32)
+    tets = (sc.tets + 1).astype(np.int32)
+    ts = ext.TetSpheres(rest.reshape(-1), tets.reshape(-1))
+    x = np.concatenate([pad + 1, scenes.deform(sc, 0.3), pad - 2, pad]).astype(np.float32)
+    e, g = _eval_gpu(ext, ts, x, 1e-4, 2e-4, 2, go=0.5)
+    O = _oracle()
+    E, _, _, g64 = O.energy_and_grad(x, O.prepare(rest, tets), 1e-4, 2e-4, 2, grad_output=0.5)
+    assert not g[0].any() and not g[-2:].any()
+    assert abs(e - E) <= 1e-5 * abs(E) and np.linalg.norm(g - g64) <= 1e-5 * np.linalg.norm(g64)
 
 
 @pytest.mark.parametrize("kind,S,kw", [("kuhn8", 8, {}), ("kuhn19", 2, {}), ("kuhn19", 2, dict(max_threads=768, lds_budget_bytes=81920)),

@@ -141,6 +141,11 @@ def test_error_behaviour(ext, capsys):
     o.struct_size = 4
     h = C.c_void_p()
     assert lib.tsamd_create(v32.ctypes.data, v32.shape[0], t.ctypes.data, t.shape[0], C.byref(o), C.byref(h)) == 1
+    # ... and a caller compiled against another ABI version is rejected even when the struct size happens to agree
+    o = _capi.make_options(host_only=1)
+    o.abi_version = _capi.ABI_VERSION - 1
+    assert lib.tsamd_create(v32.ctypes.data, v32.shape[0], t.ctypes.data, t.shape[0], C.byref(o), C.byref(h)) == 1
+    assert b"abi_version" in lib.tsamd_last_error()
 
 
 def test_train_loop_abi_checks_arguments():

@@ -134,7 +134,7 @@ def test_two_ranks_match_unsharded_oracle():
 def test_single_process_is_identity():
     rest, tets, vo, to, x = _scene()
     mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
-    assert mod.exchange == "step"                          # the job-wide value by default; the windowed exchange is an opt-in
+    assert mod.exchange == "overlap"                       # the job-wide value by default (waited for when read); windowed = opt-in
     assert mod.world_size == 1 and mod.vertex_range == (0, rest.shape[0])
     xl = torch.from_numpy(x).requires_grad_(True)
     e = mod(xl, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff)
@@ -146,6 +146,105 @@ def test_single_process_is_identity():
     xf = torch.from_numpy(x).requires_grad_(True)
     mod.forward_replicated(xf, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff).backward()
     assert np.abs(xf.grad.numpy() - g).max() <= 1e-5 * np.abs(g).max()
+
+
+def _overlap_worker(rank, world, port, out):
+    """exchange="overlap" (the default): a collective per call, issued by the helper thread; the value waits, backward() does not."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tssplat_amd.sharding import JobWideEnergy
+        rest, tets, vo, to, x = _scene()
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, depth=4)
+        assert mod.exchange == "overlap"
+        lo, hi = mod.vertex_range
+        c1, c2 = mod.coeff_scheduler(0)
+        rec = {}
+        # (1) a training-shaped loop that never reads the value: six steps with different positions
+        grads, kept = [], []
+        for k in range(6):
+            xl = torch.from_numpy(x[lo:hi] * (1.0 + 0.01 * k)).requires_grad_(True)
+            e = mod(xl, 0, c1, c2)
+            assert isinstance(e, JobWideEnergy) and e._tsamd_resolved is None
+            e.backward()                                       # rank-local gradient; must not resolve the value
+            assert e._tsamd_resolved is None
+            grads.append(xl.grad.numpy().copy())
+            kept.append(e)
+        rec["grads"] = grads
+        # (2) the values of the last `depth` calls are readable afterwards, older ones have expired (loudly)
+        rec["late"] = [float(e) for e in kept[2:]]
+        try:
+            float(kept[0])
+            rec["expired"] = False
+        except RuntimeError as exc:
+            rec["expired"] = "expired" in str(exc)
+        # (3) reading inside the step -- the reference trainer's `loss = image_loss + energy` (trainer.py:115) -- gives the job-wide
+        #     value AND the rank-local gradient, scaled
+        xl = torch.from_numpy(x[lo:hi]).requires_grad_(True)
+        e = mod(xl, 0, c1, c2)
+        loss = 3.0 + 2.0 * e
+        loss.backward()
+        rec["loss"], rec["g_loss"] = float(loss), xl.grad.numpy().copy()
+        # (4) under no_grad the call is still a collective and returns the plain job-wide value
+        with torch.no_grad():
+            en = mod(torch.from_numpy(x[lo:hi]), 0, c1, c2)
+        assert type(en) is torch.Tensor
+        rec["nograd"] = float(en)
+        # (5) replicated parameter through the same exchange
+        xf = torch.from_numpy(x).requires_grad_(True)
+        ef = mod.forward_replicated(xf, 0, c1, c2)
+        ef.backward()
+        rec["ef"], rec["g_full"] = float(ef), xf.grad.numpy().copy()
+        rec["collectives"] = mod._overlap.collectives
+        rec["range"] = (lo, hi)
+        out[rank] = rec
+        mod._overlap.drain()
+        mod._overlap.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_overlapped_exchange_job_wide_values_and_local_gradients(world):
+    from oracle import tet_energy_oracle as O
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, port, out), nprocs=world, join=True)
+    rest, tets, vo, to, x = _scene()
+    cache = O.prepare(rest, tets)
+    c1, c2 = _Flags.smooth_eng_coeff, _Flags.barrier_coeff
+    Es, gs = zip(*[(lambda r: (r[0], r[3]))(O.energy_and_grad((x * (1.0 + 0.01 * k)).astype(np.float32), cache, c1, c2, 2)) for k in range(6)])
+    E0, _, _, g0 = O.energy_and_grad(x, cache, c1, c2, 2)
+    for rank in range(world):
+        rec = out[rank]
+        lo, hi = rec["range"]
+        for k in range(6):
+            assert np.abs(rec["grads"][k] - gs[k][lo:hi]).max(initial=0.0) <= 1e-5 * np.abs(gs[k]).max() + 1e-12   # (ranks beyond the spheres own nothing)
+        assert rec["expired"] is True
+        for k, v in zip(range(2, 6), rec["late"]):
+            assert abs(v - Es[k]) <= 3e-6 * abs(Es[k]), (rank, k, v, Es[k])            # job-wide, on every rank, steps later
+        assert abs(rec["loss"] - (3.0 + 2.0 * E0)) <= 1e-5 * abs(3.0 + 2.0 * E0)
+        assert np.abs(rec["g_loss"] - 2.0 * g0[lo:hi]).max(initial=0.0) <= 2e-5 * np.abs(g0).max() + 1e-12
+        assert abs(rec["nograd"] - E0) <= 3e-6 * abs(E0) and abs(rec["ef"] - E0) <= 3e-6 * abs(E0)
+        assert np.abs(rec["g_full"] - g0).max() <= 1e-5 * np.abs(g0).max()
+        assert rec["collectives"] == 9                                                   # one per call, read or not
+
+
+def test_overlapped_exchange_single_process():
+    """No process group: the exchange is the identity, the lazy tensor behaves like the local energy."""
+    from tssplat_amd.sharding import JobWideEnergy
+    rest, tets, vo, to, x = _scene()
+    mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy)
+    xl = torch.from_numpy(x).requires_grad_(True)
+    e = mod(xl, 0, _Flags.smooth_eng_coeff, _Flags.barrier_coeff)
+    assert isinstance(e, JobWideEnergy) and e.shape == () and e.requires_grad and e.dtype == torch.float32
+    assert e._tsamd_resolved is None                                                     # metadata reads do not resolve
+    torch.autograd.backward((e, (xl * 0).sum()))                                         # trainer-shaped: two losses, no value read
+    assert e._tsamd_resolved is None and xl.grad is not None
+    assert "%.3e" % e == "%.3e" % float(e.detach()) and type(e + 1.0) is torch.Tensor   # %-formatting (trainer.py:118-125), arithmetic
+    assert mod._overlap.collectives == 0
 
 
 def test_rejects_spheres_that_share_vertices():

@@ -149,11 +149,20 @@ FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> func
     "sched_memclause": lambda f: [("-amdgpu-sched-strategy=max-memory-clause" if x == "-amdgpu-sched-strategy=max-ilp" else x) for x in f],
     "sched_iterilp": lambda f: [("-amdgpu-sched-strategy=iterative-ilp" if x == "-amdgpu-sched-strategy=max-ilp" else x) for x in f],
 }
+# -D builds: the define goes to EVERY translation unit (host and device), the source is unpatched
+DEFINE_VARIANTS = {
+    "pair16": ("planes that are loaded together interleaved per lane in the device image: six 16-byte + one 8-byte load per lane instead of thirteen 8-byte loads (plan.h: planes_paired)",
+               ["-DTSAMD_PAIRED_PLANES=1"]),
+}
+for _n, (_d, _f) in DEFINE_VARIANTS.items():
+    VARIANTS[_n] = (_d, [])
 for _n in FLAG_VARIANTS:
     VARIANTS[_n] = (f"compiler flags: {_n}", [(K, "// gfx950 (MI355X / CDNA4) kernels", "// gfx950 (MI355X / CDNA4) kernels")])
 
 
 def build(name: str) -> str:
+    if name in DEFINE_VARIANTS:
+        return _build.build_variant(name, DEFINE_VARIANTS[name][1])
     desc, patches = VARIANTS[name]
     if name in COMBOS:
         patches = [q for n in COMBOS[name] for q in VARIANTS[n][1]]

@@ -36,6 +36,7 @@ class Options(C.Structure):
         ("debug_flags", C.c_int32),
         ("slots_per_thread", C.c_int32),
         ("rebuild_dminv", C.c_int32),
+        ("abi_version", C.c_int32),
     ]
 
 
@@ -61,7 +62,7 @@ class TileView(C.Structure):
     ]
 
 
-ABI_VERSION = 2          # include/tssplat_amd.h: TSAMD_ABI_VERSION
+ABI_VERSION = 3          # include/tssplat_amd.h: TSAMD_ABI_VERSION
 
 # every symbol include/tssplat_amd.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -217,6 +218,7 @@ def check(rc: int) -> None:
 def make_options(**kw) -> Options:
     o = Options()
     o.struct_size = C.sizeof(Options)
+    o.abi_version = ABI_VERSION
     o.device = -1
     for k, v in kw.items():
         if not hasattr(o, k):

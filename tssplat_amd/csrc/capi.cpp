@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "capi_common.h"
@@ -116,12 +117,35 @@ int to_device(tsamd_handle *h, int device)
     const tsamd::Plan &P = h->plan;
     int rc;
     if ((rc = upload(h->d_tiles, P.tiles.data(), P.tiles.size(), h->device_bytes))) return rc;
-    if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(P.blob.data()), P.blob.size() * 4, h->device_bytes))) return rc;
+    if (tsamd::planes_paired(P.spt) && !P.tiles.empty()) {
+        // the device image interleaves the planes that are loaded together (plan.h: planes_paired); row tables, rest positions and
+        // the padding between tiles are copied as they are
+        tsamd::RawVector<uint32_t> image(P.blob.size());
+        const int64_t T = int64_t(P.tiles.size());
+        const int nthr = int(std::max<int64_t>(1, std::min<int64_t>({int64_t(std::thread::hardware_concurrency()), 64, T / 64 + 1})));
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nthr; ++w)
+            pool.emplace_back([&, w]() {
+                for (int64_t t = T * w / nthr; t < T * (w + 1) / nthr; ++t) {
+                    const tsamd::TileDesc &d = P.tiles[size_t(t)];
+                    const size_t b0 = size_t(d.blob_off / 4), b1 = t + 1 < T ? size_t(P.tiles[size_t(t) + 1].blob_off / 4) : P.blob.size();
+                    const size_t np = size_t(P.n_planes) * size_t(d.s_pad);
+                    tsamd::interleave_tile_planes(P.blob.data() + b0, image.data() + b0, P.n_planes, d.s_pad, P.spt);
+                    std::memcpy(image.data() + b0 + np, P.blob.data() + b0 + np, (b1 - b0 - np) * 4);
+                }
+            });
+        for (auto &th : pool) th.join();
+        const size_t head = size_t(P.tiles[0].blob_off / 4);
+        if (head) std::memcpy(image.data(), P.blob.data(), head * 4);
+        if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(image.data()), image.size() * 4, h->device_bytes))) return rc;
+    } else if ((rc = upload(h->d_blob, reinterpret_cast<const uint8_t *>(P.blob.data()), P.blob.size() * 4, h->device_bytes))) {
+        return rc;
+    }
     if ((rc = upload(h->d_gvid, P.gvid.data(), P.gvid.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_vdst, P.vdst.data(), P.vdst.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_fin_vid, P.fin_vid.data(), P.fin_vid.size(), h->device_bytes))) return rc;
     if ((rc = upload(h->d_fin_off, P.fin_off.data(), P.fin_off.size(), h->device_bytes))) return rc;
-    if ((rc = upload(h->d_stage, nullptr, size_t(P.n_stage) * 3, h->device_bytes))) return rc;
+    if ((rc = upload(h->d_stage, nullptr, size_t(P.n_stage) * 3 + 3 /* finish_kernel's look-ahead may read row 0 of an empty buffer */, h->device_bytes))) return rc;
     if ((rc = upload(h->d_partials, nullptr, P.tiles.size() * 2, h->device_bytes))) return rc;
     if ((rc = upload(h->d_terms, nullptr, 2, h->device_bytes))) return rc;
     if ((rc = upload(h->d_energy_scratch, nullptr, 1, h->device_bytes))) return rc;
@@ -147,6 +171,9 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     if (o) {
         if (o->struct_size != int32_t(sizeof(tsamd_options)))
             return fail(TSAMD_ERR_INVALID_ARGUMENT, "tsamd_options.struct_size does not match this library");
+        if (o->abi_version != TSAMD_ABI_VERSION)
+            return fail(TSAMD_ERR_INVALID_ARGUMENT, "tsamd_options.abi_version is " + std::to_string(o->abi_version) + ", this library implements ABI " +
+                                                        std::to_string(TSAMD_ABI_VERSION) + " (set it to TSAMD_ABI_VERSION of the header you compile against)");
         opt = *o;
     }
     tsamd::PlanOptions po;

@@ -333,8 +333,36 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     // lanes beyond the tile read lane 0's entries (and never use them): with every load unconditional the stream
     // is straight-line code and the compiler can count its waits (vmcnt(13)) instead of draining to vmcnt(0)
     const int lt = active ? tid : 0;
-    auto plane_u = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VU *>(pl + q * td.s_pad + SPT * lt); };
-    auto plane_f = [&](int q) { return *reinterpret_cast<const GLOBAL_AS VF *>(pl + q * td.s_pad + SPT * lt); };
+    // (a lane's SPT plane entries are loaded as one vector; the typedefs carry the alignment the address really has --
+    // SPT dwords, and only 4 bytes for SPT == 3, where clang would otherwise assume the 16 of a padded 3-vector)
+    typedef VU PlaneU __attribute__((aligned(SPT == 3 ? 4 : 4 * SPT)));
+    typedef VF PlaneF __attribute__((aligned(SPT == 3 ? 4 : 4 * SPT)));
+    auto plane_u = [&](int q) -> VU { return *reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt); };
+    auto plane_f = [&](int q) -> VF { return *reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt); };
+    // Two planes that are always loaded together are ONE load of twice the width (plan.h: planes_paired): in the device image
+    // of the blob planes q and q + 1 are interleaved per lane -- [plane q: SPT dwords | plane q + 1: SPT dwords] -- so the
+    // default layout's thirteen 8-byte loads per lane become six 16-byte loads and one 8-byte load.
+    constexpr bool kPaired = planes_paired(SPT);
+    typedef uint32_t VU2 __attribute__((ext_vector_type(2 * SPT)));
+    typedef float VF2 __attribute__((ext_vector_type(2 * SPT)));
+    auto pair_u = [&](int q, VU &lo, VU &hi) {
+        if (kPaired) {
+            const VU2 t = *reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt);
+#pragma unroll
+            for (int p = 0; p < SPT; ++p) lo[p] = t[p], hi[p] = t[SPT + p];
+        } else {
+            lo = plane_u(q), hi = plane_u(q + 1);
+        }
+    };
+    auto pair_f = [&](int q, VF &lo, VF &hi) {
+        if (kPaired) {
+            const VF2 t = *reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt);
+#pragma unroll
+            for (int p = 0; p < SPT; ++p) lo[p] = t[p], hi[p] = t[SPT + p];
+        } else {
+            lo = plane_f(q), hi = plane_f(q + 1);
+        }
+    };
     // ---- stream the tile ----
     // A CU pulls cold data at ~11 bytes per cycle whatever the rest of the chip does (tools/ubench_ingest.hip), in the order the
     // loads were issued, wave after wave.  The order below is built around that FIFO:
@@ -344,7 +372,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     //   4. the nine Dm^-1 planes: every wave computes its F as soon as ITS planes have landed;
     //   5. the neighbour planes (and an explicit operator's weights) and the row table, which nobody needs before pass 2, go
     //      out after the barrier.
-    VU q_lv01 = plane_u(0), q_lv23 = plane_u(1), q_nb01, q_nb23;
+    VU q_lv01, q_lv23, q_nb01, q_nb23;
+    pair_u(0, q_lv01, q_lv23);
     VF dm[9];
     const int kBasePlanes = REBUILD ? kPlanesRebuild : (WEIGHTED ? a.n_planes : kPlanes);   // (a compile-time constant unless WEIGHTED)
     const GLOBAL_AS uint16_t *g_rowtab = reinterpret_cast<const GLOBAL_AS uint16_t *>(pl + size_t(kBasePlanes) * td.s_pad);
@@ -364,7 +393,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     __builtin_amdgcn_sched_barrier(0);
     if (!REBUILD) {
 #pragma unroll
-        for (int c = 0; c < 9; ++c) dm[c] = plane_f(4 + c);
+        for (int c = 0; c < 8; c += 2) pair_f(4 + c, dm[c], dm[c + 1]);
+        dm[8] = plane_f(12);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (tid < td.n_verts) {
@@ -378,14 +408,14 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     }
     __syncthreads();
     // behind the barrier: what pass 2 and the end of the tile need
-    q_nb01 = plane_u(2), q_nb23 = plane_u(3);
+    pair_u(2, q_nb01, q_nb23);
     // explicit element operator (plans built with one): diagonal + the four row weights for pass 2; the column
     // weights for pass 3 replace them after pass 2
     VF wd, wk[4];
     if (WEIGHTED) {
         wd = plane_f(13);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wk[k] = plane_f(14 + k);
+        pair_f(14, wk[0], wk[1]);
+        pair_f(16, wk[2], wk[3]);
     }
     // row table: start of row `tid` of the force array, in 12-byte entries.  An unconditional load, like the planes: behind the
     // join of a divergent branch the compiler waits for EVERY load in flight, and pass 1 would start behind the neighbour planes
@@ -552,8 +582,8 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
             for (int p = 0; p < SPT; ++p) store_slot(t_own(p), H[p]);   // (zeros on halo and padding slots)
             if (WEIGHTED && a.n_planes == kPlanesWeighted) {   // pass 3 applies L^T: the column weights L[n_k, e] (a symmetric
                                                                // operator has none: the row weights serve both passes)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wk[k] = plane_f(18 + k);
+                pair_f(18, wk[0], wk[1]);
+                pair_f(20, wk[2], wk[3]);
             }
         }
         publish_wave_sums();
@@ -810,7 +840,8 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
             float3 r[kRowsAhead];
 #pragma unroll
             for (int j = 0; j < kRowsAhead; ++j) {
-                const int32_t e = e0 + j < e1 ? e0 + j : e1 - 1;
+                // (a vertex no tet references is in the list with zero rows: e1 - 1 may be -1 -- read row 0, add nothing)
+                const int32_t e = e0 + j < e1 ? e0 + j : (e1 > 0 ? e1 - 1 : 0);
                 const float *p = a.stage + size_t(e) * 3;
                 r[j] = make_float3(p[0], p[1], p[2]);
             }

@@ -122,6 +122,31 @@ inline int64_t tile_rec_base(int64_t n_verts, bool rebuild_dminv = false)
 inline uint32_t record_token(uint32_t idx, uint32_t rec_base) { return rec_base / 4u + 12u * idx + ((idx >> 3) & 3u); }
 inline uint32_t token_record(uint32_t token, uint32_t rec_base) { return (token - rec_base / 4u) / 12u; }
 
+// DEVICE IMAGE of a tile's planes.  Plan::blob (and tsamd_tile_view) hold the planes one after the other, s_pad dwords each, lane
+// t's slots at dwords [spt t, spt t + spt).  The copy in HBM interleaves the planes that the kernels always load together --
+// plane q with plane q ^ 1, for every q except the two odd ones out, 12 (the ninth entry of Dm^-1) and 13 (an explicit
+// operator's diagonal) -- per lane: dwords [2 spt t, 2 spt t + spt) of the pair's range are plane q's, the next spt plane q + 1's.
+// One 16-byte load per lane and pair instead of two 8-byte loads: the same bytes in half the requests (a CU's ingest rate is
+// requests in flight / latency, tools/ubench_ingest.hip: 13.2 against 11.4 bytes per cycle and CU with two workgroups streaming).
+// Byte ranges of planes, row table and rest positions inside the blob are the same in both layouts.
+#ifndef TSAMD_PAIRED_PLANES
+#define TSAMD_PAIRED_PLANES 0
+#endif
+TSAMD_HOST_DEVICE constexpr bool planes_paired(int spt) { return TSAMD_PAIRED_PLANES != 0 && (spt == 2 || spt == 4); }
+TSAMD_HOST_DEVICE constexpr bool plane_has_partner(int q, int n_planes) { return q != 12 && q != 13 && (q | 1) < n_planes; }
+// dst = device image of one tile's planes (n_planes * s_pad dwords) from the host layout src
+inline void interleave_tile_planes(const uint32_t *src, uint32_t *dst, int n_planes, int64_t s_pad, int spt)
+{
+    for (int q = 0; q < n_planes; ++q) {
+        if (!plane_has_partner(q, n_planes)) {
+            for (int64_t i = 0; i < s_pad; ++i) dst[q * s_pad + i] = src[q * s_pad + i];
+            continue;
+        }
+        const int q0 = q & ~1, half = q & 1;
+        for (int64_t i = 0; i < s_pad; ++i) dst[q0 * s_pad + 2 * spt * (i / spt) + half * spt + i % spt] = src[q * s_pad + i];
+    }
+}
+
 // Where slot s (HBM plane order: thread t streams slots spt*t .. spt*t+spt-1 as one load per plane) lives in
 // the LDS planes.  Lane t keeps its p-th slot at p * nq + t, so the 64 lanes of a wave touch 64
 // consecutive float4 -- conflict-free -- instead of a 64 B stride (4-way bank conflict, measured:

@@ -12,6 +12,8 @@ by world_size-2 gloo tests on CPU (tests/test_sharding_gloo.py).
 """
 from __future__ import annotations
 
+import queue
+import threading
 from typing import Callable, Sequence
 
 import numpy as np
@@ -19,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ["partition_spheres", "ShardedSmoothnessBarrierEnergy", "all_reduce_energy", "slice_replicated",
-           "WindowedEnergyAllReduce"]
+           "WindowedEnergyAllReduce", "OverlappedEnergyAllReduce", "JobWideEnergy"]
 
 
 def partition_spheres(tets_per_sphere: Sequence[int], world_size: int) -> list[tuple[int, int]]:
@@ -182,10 +184,186 @@ class WindowedEnergyAllReduce:
         return out
 
 
+class OverlappedEnergyAllReduce:
+    """One all-reduce PER STEP that costs the step nothing: issued by a helper thread on a side stream, waited for only by
+    whoever reads its result.
+
+    ``submit(local_energy)`` (the training thread) copies the scalar into a ring slot on the current stream, records an event
+    and hands (slot, event) to the helper thread -- a few microseconds, no collective call.  The helper makes a side stream
+    wait for the event and enqueues ``dist.all_reduce(slot, async_op=True)`` there (RCCL on a GPU node: the collective's own
+    stream then waits for the side stream, never for the compute stream, and the compute stream never waits for it); the
+    20-40 us a collective call costs the host (profiles/r05_scaling_model.json: 63.5 -> 89.7 us per step at 64 spheres per
+    rank) are spent next to the training thread, not in it.  ``value(ticket)`` waits -- host-side until the helper has
+    issued the collective, stream-side for its completion -- and returns the job-wide energy.  Collectives are issued in
+    ticket order by ONE thread, so every rank issues the same sequence as long as every rank submits the same sequence
+    (the rule of any collective) -- on ``group``, which must carry NOTHING else: the training thread's own collectives would
+    interleave with the helper's in a different order on every rank (``ShardedSmoothnessBarrierEnergy`` creates a group for
+    it).  A slot is re-used after ``depth`` tickets: older values have expired.
+
+    With one rank or no initialised process group the collective is the identity; everything else runs unchanged.
+    """
+
+    def __init__(self, device, group=None, depth: int = 256):
+        if depth < 2:
+            raise ValueError("depth must be >= 2")
+        self.device, self.group, self.depth = torch.device(device), group, int(depth)
+        self.ring = torch.zeros(self.depth, dtype=torch.float32, device=self.device)
+        self._cuda = self.device.type == "cuda"
+        self._side = torch.cuda.Stream(self.device) if self._cuda else None
+        self._events = [torch.cuda.Event() for _ in range(self.depth)] if self._cuda else None
+        self._works: list = [None] * self.depth
+        self._issued = [threading.Event() for _ in range(self.depth)]
+        self._ticket_of_slot = [-1] * self.depth
+        self._next = 0
+        self._q: queue.SimpleQueue = queue.SimpleQueue()
+        self._thread: threading.Thread | None = None
+        self._error: BaseException | None = None
+        self._active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= 1
+        self.collectives = 0
+
+    # ---- helper thread ----
+    def _worker(self) -> None:
+        if self._cuda:
+            torch.cuda.set_device(self.device)
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            s = item
+            try:
+                buf = self.ring[s:s + 1]
+                if self._cuda:
+                    with torch.cuda.stream(self._side):
+                        self._side.wait_event(self._events[s])
+                        self._works[s] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    self._works[s] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.collectives += 1
+            except BaseException as exc:                      # noqa: BLE001  (handed to the reader)
+                self._error = exc
+            finally:
+                self._issued[s].set()
+
+    def _settle(self, s: int) -> None:
+        """The collective that last used slot ``s`` has been issued and the CURRENT stream is ordered behind its completion."""
+        self._issued[s].wait()
+        if self._error is not None:
+            raise RuntimeError("the energy all-reduce failed in the helper thread") from self._error
+        w = self._works[s]
+        if w is not None:
+            w.wait()                                          # (RCCL: stream-side; gloo: the host waits)
+            self._works[s] = None
+
+    # ---- training thread ----
+    def submit(self, local_energy: torch.Tensor) -> int:
+        t = self._next
+        self._next += 1
+        s = t % self.depth
+        if self._ticket_of_slot[s] >= 0:
+            self._settle(s)                                   # (depth tickets old: long done; orders the overwrite behind it)
+        self.ring[s:s + 1].copy_(local_energy.detach().reshape(1), non_blocking=True)
+        self._ticket_of_slot[s] = t
+        self._issued[s].clear()
+        if not self._active:
+            self._issued[s].set()
+            return t
+        if self._cuda:
+            self._events[s].record(torch.cuda.current_stream(self.device))
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._worker, name="tssplat_amd-energy-allreduce", daemon=True)
+            self._thread.start()
+        self._q.put(s)
+        return t
+
+    def value(self, ticket: int) -> torch.Tensor:
+        """Job-wide energy of ``ticket`` (0-dim, a fresh tensor)."""
+        if not 0 <= ticket < self._next:
+            raise ValueError(f"unknown ticket {ticket}")
+        s = ticket % self.depth
+        if self._ticket_of_slot[s] != ticket:
+            raise RuntimeError(f"the job-wide energy of evaluation {ticket} has expired: {self._next - ticket} evaluations ago, the ring keeps "
+                               f"{self.depth} (read it sooner, or build the module with a larger `depth`)")
+        self._settle(s)
+        return self.ring[s].clone()
+
+    def drain(self) -> None:
+        """Every collective submitted so far has been issued and the current stream is ordered behind all of them."""
+        for s in range(self.depth):
+            if self._ticket_of_slot[s] >= 0:
+                self._settle(s)
+
+    def close(self) -> None:
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join(timeout=10)
+            self._thread = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                     # noqa: BLE001
+            pass
+
+
+def _plain(t):
+    return t.as_subclass(torch.Tensor) if isinstance(t, torch.Tensor) and type(t) is not torch.Tensor else t
+
+
+class JobWideEnergy(torch.Tensor):
+    """What ``ShardedSmoothnessBarrierEnergy.forward`` returns with ``exchange="overlap"``: a 0-dim tensor whose VALUE is the
+    job-wide energy and whose gradient is this rank's.  The all-reduce that produces the value is already on its way
+    (:class:`OverlappedEnergyAllReduce`); the tensor waits for it the first time something READS the value -- ``float(e)``,
+    ``print``, ``loss + e`` -- and never when nothing does: ``e.backward()`` (or ``torch.autograd.backward((image_loss, e))``)
+    needs no value, so a training loop whose step only back-propagates and logs every n-th energy never has the exchange on its
+    path.  Reading goes through ``__torch_function__``: every torch function except the few that only touch metadata or
+    start the backward pass gets the resolved plain tensor (forward value = job-wide energy, backward = identity to the local
+    energy)."""
+
+    _NO_VALUE = {"backward", "register_hook", "retain_grad", "requires_grad_", "ones_like", "zeros_like", "empty_like", "size", "dim",
+                 "numel", "is_floating_point", "is_complex", "element_size", "get_device", "data_ptr", "_version", "type", "stride",
+                 "storage_offset", "is_contiguous", "untyped_storage", "__hash__", "__reduce_ex__"}
+    _NO_VALUE_GETTERS = {"shape", "dtype", "device", "requires_grad", "grad_fn", "is_leaf", "grad", "ndim", "is_cuda", "is_cpu", "layout",
+                         "names", "is_sparse", "is_quantized", "is_meta", "output_nr", "_backward_hooks", "retains_grad", "is_nested", "_grad"}
+
+    @staticmethod
+    def wrap(local: torch.Tensor, reducer: "OverlappedEnergyAllReduce", ticket: int) -> "JobWideEnergy":
+        t = local.as_subclass(JobWideEnergy)                  # (an alias of `local`: stays attached to its autograd node)
+        t._tsamd_reducer, t._tsamd_ticket, t._tsamd_resolved = reducer, ticket, None
+        return t
+
+    def resolve(self) -> torch.Tensor:
+        """The plain tensor: job-wide value (waits for the exchange), rank-local gradient."""
+        red = getattr(self, "_tsamd_reducer", None)
+        with torch._C.DisableTorchFunctionSubclass():
+            plain = self.as_subclass(torch.Tensor)
+            if red is None:                                   # (a by-product such as ones_like(e): an ordinary tensor)
+                return plain
+            if self._tsamd_resolved is None:
+                self._tsamd_resolved = _AddGlobal.apply(plain, red.value(self._tsamd_ticket))
+            return self._tsamd_resolved
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        owner = getattr(func, "__self__", None)               # property getters arrive as `<getset_descriptor>.__get__`
+        if name in cls._NO_VALUE or (name == "__get__" and getattr(owner, "__name__", "") in cls._NO_VALUE_GETTERS):
+            with torch._C.DisableTorchFunctionSubclass():
+                return _plain(func(*args, **kwargs))
+        scalar_read = name in ("item", "__float__", "__int__", "__bool__", "__format__", "tolist", "__repr__", "__str__")
+        res = lambda a: (a.resolve().detach() if scalar_read else a.resolve()) if isinstance(a, JobWideEnergy) else a   # noqa: E731
+        args = tuple(type(a)(res(b) for b in a) if isinstance(a, (list, tuple)) else res(a) for a in args)
+        kwargs = {k: res(v) for k, v in kwargs.items()}
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
 class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
-    """``SmoothnessBarrierEnergy`` over this rank's spheres; ``forward`` returns the JOB-WIDE energy (one scalar all-reduce per
-    step, ``exchange="step"``, the default) or, as an explicit opt-in, the rank-local one with the reduction batched
-    over steps (``exchange="window"``).
+    """``SmoothnessBarrierEnergy`` over this rank's spheres; ``forward`` returns the JOB-WIDE energy -- one scalar all-reduce per
+    call, issued next to the training thread and waited for only when the value is read (``exchange="overlap"``, the default:
+    :class:`JobWideEnergy`), or inside the call (``exchange="step"``) -- or, as an explicit opt-in, the rank-local one with the
+    reduction batched over steps (``exchange="window"``).  ``graph=True`` replays the rank's evaluation from a HIP graph behind
+    the autograd node (``SmoothnessBarrierEnergy(graph=True)``).
 
     Parameters mirror the reference module (/root/reference/energies/smooth_barrier.py:34-45) plus
     the sphere layout: ``sphere_vertex_offsets`` / ``sphere_tet_offsets`` (``S+1`` entries each,
@@ -203,12 +381,16 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
 
     def __init__(self, tet_v, tet_f, FLAGS, sphere_vertex_offsets, sphere_tet_offsets, group=None,
                  rank: int | None = None, world_size: int | None = None,
-                 local_factory: Callable | None = None, exchange: str = "step", window: int = 16):
+                 local_factory: Callable | None = None, exchange: str = "overlap", window: int = 16, depth: int = 256,
+                 graph: bool = False, **local_kwargs):
         super().__init__()
-        if exchange not in ("window", "step"):
-            raise ValueError("exchange must be 'window' (one collective per `window` steps, off the step's path) or "
-                             "'step' (one blocking-order all-reduce per step, job-wide value returned at once)")
-        self.exchange, self.window = exchange, int(window)
+        if exchange not in ("overlap", "window", "step"):
+            raise ValueError("exchange must be 'overlap' (one all-reduce per call issued off the training thread, the job-wide value "
+                             "waited for when it is read), 'step' (the same all-reduce inside the call) or 'window' (rank-local "
+                             "value; one collective per `window` steps, job-wide values from reduced_energies())")
+        self.exchange, self.window, self.depth = exchange, int(window), int(depth)
+        self._overlap = None                     # OverlappedEnergyAllReduce, created on the first forward (needs the device)
+        self._energy_group = group
         self.max_pending = 64                    # reduced windows kept for reduced_energies() (exchange="window")
         self._reducer = None                     # WindowedEnergyAllReduce, created on the first forward (needs the device)
         initialised = dist.is_available() and dist.is_initialized()
@@ -219,6 +401,15 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         to = np.asarray(sphere_tet_offsets, dtype=np.int64)
         if vo.size != to.size or vo.size < 1:
             raise ValueError("sphere offset arrays must both have S+1 entries")
+        if exchange == "overlap" and initialised and dist.get_world_size(group) > 1:
+            # The helper thread's all-reduces need a communicator of their own: collectives of one group are matched by the ORDER in
+            # which each rank issues them, and the training thread issues others meanwhile (forward_replicated's all-gather, a
+            # data-parallel wrapper's gradient buckets) -- which of the two threads comes first differs from rank to rank.
+            # (Collective: every rank of `group` constructs the module.)
+            if group is None:
+                self._energy_group = dist.new_group()
+            else:
+                self._energy_group = dist.new_group(ranks=dist.get_process_group_ranks(group), use_local_synchronization=True)
         self.ranges = partition_spheres(np.diff(to), self.world_size)
         lo, hi = self.ranges[self.rank]
         self.sphere_range = (lo, hi)
@@ -231,8 +422,11 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
             raise ValueError("a tet references a vertex outside its sphere range: spheres must not share vertices")
         if local_factory is None:
             from .energies import SmoothnessBarrierEnergy
-            local_factory = SmoothnessBarrierEnergy
-        self.local = local_factory(v, f, FLAGS) if v.shape[0] else None
+            self.local = SmoothnessBarrierEnergy(v, f, FLAGS, graph=graph, **local_kwargs) if v.shape[0] else None
+        else:
+            if graph or local_kwargs:
+                raise TypeError("graph= and TetSpheres options go to the default local evaluator; a local_factory builds its own")
+            self.local = local_factory(v, f, FLAGS) if v.shape[0] else None
         self.FLAGS = FLAGS
 
     def coeff_scheduler(self, it):
@@ -247,8 +441,13 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         return self.forward(slice_replicated(x_full, self.vertex_ranges, self.rank, self.group), it, c1, c2)
 
     def forward(self, x_local: torch.Tensor, it, c1, c2):
-        """``exchange="step"`` (default): one all-reduce per call, the JOB-WIDE energy is the returned value; its gradient is
-        the rank-local gradient.  Every rank must make the call (it is a collective).
+        """``exchange="overlap"`` (default): one all-reduce per call, the JOB-WIDE energy is the value of the returned
+        :class:`JobWideEnergy`, its gradient the rank-local gradient.  The call itself only files the local energy (a 4-byte
+        device copy and an event); a helper thread issues the collective on a side stream, and the returned tensor waits for it
+        when -- and only if -- its value is read.  ``e.backward()`` reads nothing.  Every rank must make the call, in the same
+        order (it is a collective); calls under ``torch.no_grad()`` are collectives like any other and return the plain job-wide
+        value.  The values of the last ``depth`` calls stay readable.
+        ``exchange="step"``: the same all-reduce issued and waited for inside the call (stream-side); returns a plain tensor.
         ``exchange="window"`` (opt-in): returns THIS RANK's energy -- same gradient, which is all an optimiser needs --
         and files it into a :class:`WindowedEnergyAllReduce`: one asynchronous collective per ``window`` steps, nothing on
         the step's critical path; :meth:`reduced_energies` hands out the job-wide energies of the steps evaluated so far
@@ -264,6 +463,13 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         if self.exchange == "step":
             e_global = all_reduce_energy(e_local, self.group)
             return _AddGlobal.apply(e_local, e_global)
+        if self.exchange == "overlap":
+            if self._overlap is None:
+                self._overlap = OverlappedEnergyAllReduce(e_local.device, self._energy_group, self.depth)
+            ticket = self._overlap.submit(e_local)
+            if not (torch.is_grad_enabled() and e_local.requires_grad):
+                return self._overlap.value(ticket)
+            return JobWideEnergy.wrap(e_local, self._overlap, ticket)
         if not torch.is_grad_enabled():
             return e_local
         if self._reducer is None:
