@@ -65,9 +65,11 @@ def parse(argv=None):
     p.add_argument("--order", type=int, default=2)
     p.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto",
                    help="auto = strong (the fixed 512-sphere scene split over the ranks)")
-    p.add_argument("--launch", choices=["auto", "graph", "eager", "graph-autograd"], default="auto",
+    p.add_argument("--launch", choices=["auto", "graph", "eager", "graph-autograd", "module"], default="auto",
                    help="auto = graph replay or eager autograd, whichever is faster on this batch (measured during setup); "
-                        "graph-autograd = SmoothnessBarrierEnergy(graph=True) + backward(): the replay behind an autograd node")
+                        "graph-autograd = SmoothnessBarrierEnergy(graph=True) + backward(): the replay behind an autograd node; "
+                        "module = ShardedSmoothnessBarrierEnergy(graph=True, exchange='overlap').forward + backward(): what a trainer "
+                        "would call, the energy exchange issued by the module itself (one all-reduce per step, off the training thread)")
     p.add_argument("--max-threads", type=int, default=0)
     p.add_argument("--lds-budget", type=int, default=0)
     p.add_argument("--target-owned", type=int, default=0)
@@ -358,7 +360,7 @@ def _run_rank(args, stdout_fd: int) -> None:
             raw()
 
     graphed = None
-    if args.launch in ("auto", "graph", "graph-autograd"):
+    if args.launch in ("auto", "graph", "graph-autograd", "module"):
         try:
             graphed = GraphedSmoothnessBarrier(energy, x)
             graphed.step(it)
@@ -367,14 +369,29 @@ def _run_rank(args, stdout_fd: int) -> None:
             log(f"HIP graph capture failed ({exc!r}); using --launch eager")
             graphed = None
 
-    if world > 1 and args.launch in ("auto", "graph", "graph-autograd"):   # every rank must take the same path through the probes below
+    if world > 1 and args.launch in ("auto", "graph", "graph-autograd", "module"):   # every rank must take the same path through the probes below
         ok = torch.tensor([1 if graphed is not None else 0], device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             graphed = None
 
-    from tssplat_amd.sharding import WindowedEnergyAllReduce
-    reducer = WindowedEnergyAllReduce(max(1, args.energy_window), dev) if use_coll else None
+    from tssplat_amd.sharding import ShardedSmoothnessBarrierEnergy, WindowedEnergyAllReduce
+    reducer = WindowedEnergyAllReduce(max(1, args.energy_window), dev) if use_coll and args.launch != "module" else None
+    sharded = None
+    if args.launch == "module":
+        import numpy as np
+        # The module a trainer would hold: this rank's spheres are all this process built, so the module sees them as ITS share
+        # (rank 0 of 1 for the partition) while its energy exchange runs over the job's process group.
+        energy.graph = graphed is not None
+        sharded = ShardedSmoothnessBarrierEnergy(np.zeros((n_local, 3), np.float32), np.zeros((0, 4), np.int32), Flags, [0, n_local], [0, 0],
+                                                 rank=0, world_size=1, local_factory=lambda v, f, F: energy, exchange="overlap")
+
+    def step_module(i):
+        x.grad = None
+        a, b = coeffs(i)
+        e = sharded(x, it0 + i % 900, a, b)   # JobWideEnergy: the all-reduce is on its way, nobody waits for it here
+        e.backward()
+        return e
 
     def step_eager(i):
         x.grad = None
@@ -421,6 +438,8 @@ def _run_rank(args, stdout_fd: int) -> None:
             e = step(fn, warmup + i)
         if reducer is not None:
             reducer.flush()                 # the last (partial) window's collective is issued inside the timed region
+        if sharded is not None and sharded._overlap is not None:
+            sharded._overlap.drain()        # every step's collective issued and completed inside the timed region
         fence()
         el = time.perf_counter() - t0
         timed.local = el
@@ -430,7 +449,7 @@ def _run_rank(args, stdout_fd: int) -> None:
             el = float(tmax.item())
         return el, e
 
-    launch_mode = args.launch if graphed is not None else "eager"
+    launch_mode = args.launch if graphed is not None or args.launch == "module" else "eager"
     probe = {}
     if launch_mode == "auto":                          # a few steps of each, after a pre-heat; ranks agree on rank 0's choice
         for name, fn in (("graph", step_graph), ("eager", step_eager)):
@@ -444,13 +463,26 @@ def _run_rank(args, stdout_fd: int) -> None:
         if world > 1:
             dist.broadcast(pick, src=0)
         launch_mode = "graph" if int(pick.item()) == 0 else "eager"
-    main_fn = {"graph": step_graph, "eager": step_eager, "graph-autograd": step_graph_autograd}[launch_mode]
+    main_fn = {"graph": step_graph, "eager": step_eager, "graph-autograd": step_graph_autograd, "module": step_module}[launch_mode]
     preheat()
     elapsed, e_last = timed(main_fn, args.steps, args.warmup)
     elapsed_local = timed.local
     e_val = float(e_last)
     # the collective's result = sum of the rank energies (checked, not just issued)
     e_global = e_val
+    if sharded is not None:
+        # the module's own exchange: the value of the LAST step's JobWideEnergy (read now, long after the step) against the sum of
+        # the rank-local energies of that step
+        from tssplat_amd.sharding import JobWideEnergy
+        assert isinstance(e_last, JobWideEnergy) and sharded._overlap.collectives >= (args.steps if use_coll else 0)
+        e_loc = e_last.as_subclass(torch.Tensor).detach().clone().reshape(1)
+        parts = [torch.zeros(1, device=dev) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(parts, e_loc)
+        else:
+            parts = [e_loc]
+        e_sum = sum(float(p) for p in parts)
+        assert abs(e_global - e_sum) <= 1e-5 * abs(e_sum) + 1e-30, f"job-wide energy {e_global} != sum of rank energies {e_sum}"
     if reducer is not None:
         reduced = reducer.results()
         assert reduced.numel() == args.steps, (reduced.numel(), args.steps)
@@ -466,7 +498,7 @@ def _run_rank(args, stdout_fd: int) -> None:
     others = {}
     if world == 1:                                     # the other launch modes, for the record
         for name, fn in (("eager_autograd", step_eager), ("graph_replay", step_graph), ("graph_autograd", step_graph_autograd)):
-            if fn is main_fn or (graphed is None and fn is not step_eager):
+            if fn is main_fn or (graphed is None and fn is not step_eager) or sharded is not None:
                 continue
             preheat()
             others[name + "_ms_per_step"] = 1e3 * timed(fn, args.steps, min(args.warmup, 5))[0] / args.steps
@@ -546,11 +578,16 @@ def _run_rank(args, stdout_fd: int) -> None:
                             f"energy + full gradient per step",
                 "launch": {"graph": "HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier.step)",
                            "eager": "eager: SmoothnessBarrierEnergy + backward() through torch.autograd",
-                           "graph-autograd": "SmoothnessBarrierEnergy(graph=True) + backward(): HIP-graph replay behind an autograd node"}[launch_mode],
+                           "graph-autograd": "SmoothnessBarrierEnergy(graph=True) + backward(): HIP-graph replay behind an autograd node",
+                           "module": "ShardedSmoothnessBarrierEnergy(graph=%s, exchange='overlap').forward + backward()" % (graphed is not None)}[launch_mode],
                 "schedule": "coefficients follow coeff_scheduler(it) and change every step (replays update them as kernel-node arguments, no device traffic)",
                 "energy_exchange": (f"per-step local energies into a ring of {reducer.window} device slots, one all-reduce per window "
                                     f"({reducer.collectives} collectives so far, backend {dist.get_backend()}, {dist.get_world_size()} rank(s))"
-                                    if reducer is not None else "none (one rank, no process group)"),
+                                    if reducer is not None else
+                                    (f"the module's own: one all-reduce per step issued by a helper thread on a side stream, the job-wide value waited for "
+                                     f"when read ({sharded._overlap.collectives} collectives, "
+                                     + (f"backend {dist.get_backend()}, {dist.get_world_size()} rank(s))" if use_coll else "no process group)"))
+                                    if sharded is not None else "none (one rank, no process group)"),
                 "spheres_rank0": my_spheres,
                 "tets_rank0": m_local,
                 "vertices_rank0": n_local,

@@ -76,7 +76,10 @@ typedef struct tsamd_options {
                                 * CU) and 4 (max_threads <= 768): fewer, fatter waves, built-in operator only -- with lds_budget_bytes
                                 * up to 163840 these hold a whole ~3 k-tet sphere as ONE tile (no halo, no shared vertices).
                                 * Anything else is TSAMD_ERR_INVALID_ARGUMENT. */
-    int32_t rebuild_dminv;     /* 1 = keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
+    int32_t rebuild_dminv;     /* 0 = auto: stream Dm^-1, except for plans of 513 ... 2 048 tiles built with default tiling options,
+                                * which rebuild it (a few rounds of workgroups: 256 x 3 k-tet spheres 24.8 -> 22.8 us per step);
+                                * 2 = always stream; 1 = always rebuild:
+                                * keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
                                 * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per
                                 * evaluation, entries of Dm^-1 within 2.8e-7 relative of the exact inverse instead of
                                 * 5.9e-8 (double -> fp32 rounding, tet_spheres.cpp:43-45).  Not with an explicit operator. */
@@ -205,6 +208,10 @@ typedef struct tsamd_graph tsamd_graph;
 int tsamd_graph_create(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, int order, float *energy_dev,
                        float *grad_dev, tsamd_graph **out);
 int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream);
+/* The same replay, with the energy ALSO written to energy_copy_dev (one float; NULL = tsamd_graph_launch): a per-launch argument
+ * like the coefficients.  It is how an energy exchange across GPUs gets this launch's value into its own ring slot without a
+ * copy on the stream (tssplat_amd/sharding.py: OverlappedEnergyAllReduce).  Requires a graph created with energy_dev. */
+int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev);
 void tsamd_graph_destroy(tsamd_graph *graph);
 
 /* n_iters optimisation steps as ONE HIP graph: per step the evaluation above (energy into energy_ring_dev[k], gradient into

@@ -979,3 +979,53 @@ def test_graph_replay_back_to_back_without_sync(ext):
     assert torch.equal(e_out, e_ref), int((e_out != e_ref).sum())
     assert torch.equal(g_out, g_ref), int((g_out != g_ref).sum())
     assert len(set(e_ref.tolist())) > 300                        # the schedule really moved the result from launch to launch
+
+
+def test_sharded_module_with_its_own_exchange_on_gpu():
+    """ShardedSmoothnessBarrierEnergy(graph=True, exchange="overlap") forward + backward() on the device, through a real (single
+    rank) RCCL process group: the helper thread, the side stream and the lazily read job-wide value -- `bench.py --launch module
+    --force-collective` asserts that the value of the last step's JobWideEnergy, read after the loop, equals the sum of the rank
+    energies and that one collective per step was issued."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scene", "kuhn8", "--spheres", "16", "--launch", "module", "--force-collective",
+                        "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-3000:]
+    rec = json.loads(lines[-1])
+    assert rec["config"]["launch"].startswith("ShardedSmoothnessBarrierEnergy(graph=True")
+    assert "helper thread" in rec["config"]["energy_exchange"] and "nccl" in rec["config"]["energy_exchange"]
+    assert rec["value"] > 0 and np.isfinite(rec["energy"])
+
+
+def test_sharded_module_value_and_gradient_on_gpu(ext):
+    """The same module in-process (no process group: the exchange is the identity): value and gradient against the oracle, the
+    replayed and the eager local evaluator, reading the value late."""
+    from tssplat_amd import scenes
+    from tssplat_amd.sharding import JobWideEnergy, ShardedSmoothnessBarrierEnergy
+    sc = scenes.make_scene("kuhn8", 6)
+
+    class Flags:
+        smooth_eng_coeff, barrier_coeff, increase_order_iter = 2e-4 / 6, 2e-4, 1000
+
+    vo = sc.sphere_vertex_offsets
+    to = np.arange(7) * (sc.n_tets // 6)
+    O = _oracle()
+    cache = O.prepare(sc.rest, sc.tets)
+    for graph in (False, True):
+        mod = ShardedSmoothnessBarrierEnergy(sc.rest, sc.tets, Flags, vo, to, graph=graph)
+        x = torch.nn.Parameter(torch.from_numpy(scenes.deform(sc, 0.1)).cuda())
+        kept = []
+        for it in (0, 1, 2):
+            x.grad = None
+            c1, c2 = mod.coeff_scheduler(it)
+            e = mod(x, it, c1, c2)
+            assert isinstance(e, JobWideEnergy)
+            e.backward()
+            kept.append((e, c1, c2, x.grad.detach().cpu().numpy().astype(np.float64)))
+        for e, c1, c2, g in kept:                              # values read after the loop: they come from the exchange's ring
+            E, _, _, g64 = O.energy_and_grad(x.detach().cpu().numpy(), cache, c1, c2, 2)
+            assert abs(float(e) - E) <= 1e-5 * abs(E), (graph, float(e), E)
+            assert np.linalg.norm(g - g64) <= 2e-5 * np.linalg.norm(g64)

@@ -247,6 +247,100 @@ def test_overlapped_exchange_single_process():
     assert mod._overlap.collectives == 0
 
 
+class _OracleEnergyDirect(_OracleEnergy):
+    """The stand-in with the engine-free protocol of SmoothnessBarrierEnergy(graph=True).evaluate_direct: static buffers, a validity
+    callable, the energy written into the exchange's slot as well."""
+
+    def __init__(self, tet_v, tet_f, FLAGS):
+        super().__init__(tet_v, tet_f, FLAGS)
+        self.ticket, self.e_buf, self.g_buf, self.direct_calls = 0, torch.zeros(()), None, 0
+
+    def evaluate_direct(self, x, it, c1, c2, energy_copy=None):
+        from oracle import tet_energy_oracle as O
+        E, _, _, g = O.energy_and_grad(x.detach().numpy(), self.cache, c1, c2, 4 if it > self.FLAGS.increase_order_iter else 2)
+        if self.g_buf is None:
+            self.g_buf = torch.zeros_like(x.detach())
+        self.e_buf.fill_(float(E))
+        self.g_buf.copy_(torch.from_numpy(g.astype(np.float32)))
+        if energy_copy is not None:
+            energy_copy.fill_(float(E))
+        self.ticket += 1
+        self.direct_calls += 1
+        t = self.ticket
+        return self.e_buf, self.g_buf, (lambda: self.ticket == t)
+
+
+def _direct_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tssplat_amd.sharding import JobWideEnergy
+        rest, tets, vo, to, x = _scene()
+        mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergyDirect)
+        lo, hi = mod.vertex_range
+        c1, c2 = mod.coeff_scheduler(0)
+        rec = {}
+        xl = torch.nn.Parameter(torch.from_numpy(x[lo:hi].copy()))
+        e = mod(xl, 0, c1, c2)
+        assert isinstance(e, JobWideEnergy) and not e.requires_grad and e._tsamd_direct is not None
+        e.backward()                                           # engine-free: the buffer goes to x.grad
+        assert e._tsamd_resolved is None
+        g1 = xl.grad.numpy().copy()
+        e.backward()                                           # a second call accumulates, as autograd would
+        rec["g1"], rec["g2"] = g1, xl.grad.numpy().copy()
+        assert xl.grad.data_ptr() != mod.local.g_buf.data_ptr()
+        rec["value"] = float(e)                                # read late: job-wide
+        # trainer.py:115 shape: the value takes part in a loss -> attached through an ordinary node, scaled gradient
+        xl.grad = None
+        e2 = mod(xl, 0, c1, c2)
+        (3.0 + 2.0 * e2).backward()
+        rec["g_loss"] = xl.grad.numpy().copy()
+        # a newer evaluation invalidates the older one's gradient, loudly
+        e3 = mod(xl, 0, c1, c2)
+        _ = mod(xl, 0, c1, c2)
+        try:
+            e3.backward()
+            rec["stale"] = False
+        except RuntimeError as exc:
+            rec["stale"] = "overwritten" in str(exc)
+        # a parameter with a hook is none of the fast path's business: the ordinary autograd path, same numbers
+        calls = mod.local.direct_calls if mod.local is not None else 0
+        xh = torch.nn.Parameter(torch.from_numpy(x[lo:hi].copy()))
+        seen = []
+        xh.register_hook(lambda g: seen.append(1))
+        eh = mod(xh, 0, c1, c2)
+        assert eh.requires_grad and (mod.local is None or mod.local.direct_calls == calls)
+        eh.backward()
+        rec["g_hook"], rec["hook_ran"] = xh.grad.numpy().copy(), len(seen) == 1
+        rec["range"] = (lo, hi)
+        out[rank] = rec
+        mod._overlap.drain()
+        mod._overlap.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_free_backward_of_the_overlapped_module():
+    from oracle import tet_energy_oracle as O
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_direct_worker, args=(world, port, out), nprocs=world, join=True)
+    rest, tets, vo, to, x = _scene()
+    E0, _, _, g0 = O.energy_and_grad(x, O.prepare(rest, tets), _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2)
+    tol = 1e-5 * np.abs(g0).max()
+    for rank in range(world):
+        rec = out[rank]
+        lo, hi = rec["range"]
+        assert np.abs(rec["g1"] - g0[lo:hi]).max() <= tol and np.abs(rec["g2"] - 2.0 * g0[lo:hi]).max() <= 2 * tol
+        assert abs(rec["value"] - E0) <= 3e-6 * abs(E0)
+        assert np.abs(rec["g_loss"] - 2.0 * g0[lo:hi]).max() <= 2 * tol
+        assert rec["stale"] is True and rec["hook_ran"] is True
+        assert np.abs(rec["g_hook"] - g0[lo:hi]).max() <= tol
+
+
 def test_rejects_spheres_that_share_vertices():
     rest, tets, vo, to, _ = _scene()
     bad = tets.copy()

@@ -2,7 +2,7 @@
 # Condense the raw output of tools/profile_round.sh (gpurun_out/<round>p/, scratch) into the tracked files under profiles/.
 #   bash tools/collect_round.sh r05
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 O=gpurun_out/${ROUND}p
 for w in kuhn19x512 avegx952 delaunay6000x540 kuhn8x256 kuhn8x64; do
   extra=""

@@ -38,6 +38,23 @@ VARIANTS = {
         (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            if (v < td.n_verts && gx == 12345.678f) {\n                const bool excl = row >= 0;")]),
     "nopen3": ("pricing: the inverted-tet branch of pass 3 (F rebuilt, cofactor) skipped -- what moving it out of stage B could buy at most", [
         (K, "                if (scal[p] != 0.f) {  // inverted owned tet: rebuild F", "                if (scal[p] == 12345.678f) {  // inverted owned tet: rebuild F")]),
+    # ---- round 6: what could ANY design that hides the stream reach?  (profiles/r06_experiments.md) ----
+    "nostream": ("pricing: every tile reads tile 0's planes (L2 hits: the stream costs almost nothing, results wrong) at the production occupancy -- "
+                 "the floor of a PERFECT next-tile prefetch with two workgroups per CU", [
+        (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));")]),
+    "onewg": ("pricing: ONE workgroup per CU (100 KiB of dynamic LDS requested per workgroup, same tiles, same kernel)", [
+        (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
+        (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "onewg_nostream": ("pricing: one workgroup per CU AND no stream -- the floor of the LDS-DMA loader / consumer design (a CU's LDS holds ONE tile's records "
+                       "next to the next tile's ring; 1 024 threads per workgroup cap the consumers at 12 waves + 4 loaders)", [
+        (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));"),
+        (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
+        (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "ntplanes": ("candidate: non-temporal loads for the planes (each is read once, by one CU)", [
+        (K, "            const VU2 t = *reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt);",
+            "            const VU2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt));"),
+        (K, "            const VF2 t = *reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt);",
+            "            const VF2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt));")]),
     # ---- candidates ----
     "stagger": ("the second workgroup of every CU starts half a tile late (first 512 workgroups: 256-511 sleep ~2.7 us)", [
         (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",
@@ -151,8 +168,8 @@ FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> func
 }
 # -D builds: the define goes to EVERY translation unit (host and device), the source is unpatched
 DEFINE_VARIANTS = {
-    "pair16": ("planes that are loaded together interleaved per lane in the device image: six 16-byte + one 8-byte load per lane instead of thirteen 8-byte loads (plan.h: planes_paired)",
-               ["-DTSAMD_PAIRED_PLANES=1"]),
+    "unpaired": ("the device image of rounds 1-5: planes one after the other, thirteen 8-byte loads per lane (the product interleaves the planes that are "
+                 "loaded together: six 16-byte + one 8-byte load, plan.h: planes_paired)", ["-DTSAMD_PAIRED_PLANES=0"]),
 }
 for _n, (_d, _f) in DEFINE_VARIANTS.items():
     VARIANTS[_n] = (_d, [])

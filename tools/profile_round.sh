@@ -3,7 +3,7 @@
 # report, bench lines.   gpurun -- 'bash tools/profile_round.sh r05'
 # Raw output lands in gpurun_out/<round>p/; tools/collect_round.sh condenses it into profiles/.
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/${ROUND}p
 mkdir -p $OUT
@@ -12,7 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_kuhn19x512 -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats_kuhn19x512.log 2>&1
 for cfg in "kuhn19 512" "aveg 952" "delaunay6000 540" "kuhn8 256" "kuhn8 64"; do set -- $cfg
   W=$1x$2
-  [ "$W" != "kuhn19x512" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 40 > $OUT/stats_$W.log 2>&1
+  # (>= 500 launches behind a pre-heat, like the headline run: 40 cold launches showed the clock ramp)
+  [ "$W" != "kuhn19x512" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --preheat-ms 150 --evals 600 > $OUT/stats_$W.log 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_fetch_$W.log 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write_$W -- python $R/tools/run_eval.py --scene $1 --spheres $2 --evals 6 > $OUT/pmc_write_$W.log 2>&1
 done

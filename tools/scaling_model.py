@@ -54,6 +54,11 @@ def main():
         for key, tag in (("eager_autograd", "eager"), ("graph_replay", "HIP-graph replay of"), ("graph_autograd", "SmoothnessBarrierEnergy(graph=True)")):
             if t[key] is None and rec["config"]["launch"].startswith(tag):
                 t[key] = rec["ms_per_step"]
+        # the module a trainer would hold, with its own energy exchange (one all-reduce per step off the training thread):
+        # ShardedSmoothnessBarrierEnergy(graph=True, exchange="overlap").forward + backward()  
+        mod = run(s, args.steps, args.window, ("--launch", "module"))
+        t["sharded_module"] = mod["ms_per_step"]
+        t["sharded_module_exchange"] = mod["config"]["energy_exchange"]
         rows[n] = {"spheres_per_rank": s, **t}
         print(n, json.dumps(rows[n]), flush=True)
     one = rows[1]
@@ -61,7 +66,7 @@ def main():
     for n in (2, 4, 8):
         r = rows[n]
         model[str(n)] = {k: (one[k] / r[k] if one.get(k) and r.get(k) else None)
-                         for k in ("main", "eager_autograd", "graph_replay", "graph_autograd", "tile_kernel_ms")}
+                         for k in ("main", "eager_autograd", "graph_replay", "graph_autograd", "sharded_module", "tile_kernel_ms")}
         best1 = min(v for v in (one["eager_autograd"], one["graph_replay"], one["graph_autograd"]) if v)
         bestn = min(v for v in (r["eager_autograd"], r["graph_replay"], r["graph_autograd"]) if v)
         model[str(n)]["best_mode_each"] = best1 / bestn

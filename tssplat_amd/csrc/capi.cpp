@@ -189,11 +189,12 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
         if (!tsamd::lane_layout_supported(spt, opt.max_threads > 0 ? opt.max_threads : tsamd::kTileThreads))
             return fail(TSAMD_ERR_INVALID_ARGUMENT, "max_threads exceeds what the tile kernels are compiled for at " + std::to_string(spt) +
                                                         " slots per thread (2: 768, 3: 1024, 4: 768)");
-        if (spt != tsamd::kSlotsPerLane && (op || opt.rebuild_dminv))
+        if (spt != tsamd::kSlotsPerLane && (op || opt.rebuild_dminv == 1))
             return fail(TSAMD_ERR_INVALID_ARGUMENT, "slots_per_thread 3 and 4 are built for the built-in operator with streamed Dm^-1 only");
         po.slots_per_lane = spt;
     }
-    po.rebuild_dminv = opt.rebuild_dminv ? 1 : 0;
+    if (opt.rebuild_dminv < 0 || opt.rebuild_dminv > 2) return fail(TSAMD_ERR_INVALID_ARGUMENT, "rebuild_dminv must be 0 (auto), 1 (rebuild) or 2 (stream)");
+    po.rebuild_dminv = opt.rebuild_dminv == 1 ? 1 : 0;
     tsamd_handle *h = new (std::nothrow) tsamd_handle();
     if (!h) return fail(TSAMD_ERR_INVALID_ARGUMENT, "out of host memory");
     std::string err;
@@ -222,7 +223,28 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
             rc2 = tsamd::build_plan(rest, n, tets, m, po2, alt, err2, op);
         } catch (const std::bad_alloc &) {
         }
-        if (rc2 == 0 && alt.tiles.size() > h->plan.tiles.size() && alt.tiles.size() <= 2048) h->plan = std::move(alt);
+        if (rc2 == 0 && alt.tiles.size() > h->plan.tiles.size() && alt.tiles.size() <= 2048) {
+            h->plan = std::move(alt);
+            po = po2;
+        }
+    }
+    // Mid-size batches (rebuild_dminv = 0, "auto"): a plan of a few rounds of workgroups (more than the 512 the chip holds at once,
+    // at most 2 048) neither hides a tile's stream behind thousands of others nor is it a single tile's latency -- there the 36 of 52
+    // bytes per slot that rebuild_dminv does not stream win: 256 x kuhn8 24.8 -> 22.8 us per step (64 x kuhn8, one round: 14.3 ->
+    // 14.7, stays streamed; the 21 M-tet scene: +15 %, stays streamed; profiles/r06_experiments.md).  Built-in operator, default
+    // lane layout and tiling options only; 1 / 2 force either form.
+    if (opt.rebuild_dminv == 0 && !op && po.slots_per_lane == tsamd::kSlotsPerLane && opt.max_threads == 0 && opt.target_owned == 0 &&
+        opt.lds_budget_bytes == 0 && h->plan.tiles.size() > 512 && h->plan.tiles.size() <= 2048) {
+        tsamd::PlanOptions po3 = po;
+        po3.rebuild_dminv = 1;
+        tsamd::Plan alt;
+        std::string err3;
+        int rc3 = 1;
+        try {
+            rc3 = tsamd::build_plan(rest, n, tets, m, po3, alt, err3, op);
+        } catch (const std::bad_alloc &) {
+        }
+        if (rc3 == 0 && alt.tiles.size() <= 2048) h->plan = std::move(alt);
     }
     if (!opt.host_only) {
         rc = to_device(h, opt.device);
@@ -464,6 +486,18 @@ int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream)
     DeviceGuard g;
     TSAMD_HIP(g.enter(graph->device));
     TSAMD_HIP(tsamd::eval_graph_launch(graph->g, c1, c2, static_cast<hipStream_t>(stream)));
+    return TSAMD_OK;
+}
+
+int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev)
+{
+    if (!graph || !graph->g) return fail(TSAMD_ERR_INVALID_ARGUMENT, "graph is null");
+    DeviceGuard g;
+    TSAMD_HIP(g.enter(graph->device));
+    const hipError_t e = tsamd::eval_graph_launch(graph->g, c1, c2, static_cast<hipStream_t>(stream), energy_copy_dev);
+    if (e == hipErrorInvalidValue && energy_copy_dev)
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "this graph has no node that writes the energy (created without energy_dev on an empty plan)");
+    TSAMD_HIP(e);
     return TSAMD_OK;
 }
 

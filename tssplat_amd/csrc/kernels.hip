@@ -763,6 +763,7 @@ struct FinishArgs {
     const float *coef;  // optional device (c1, c2), see KernelArgs
     float *energy;
     double *terms;
+    float *energy_copy;   // optional second destination of the energy (a replay's per-launch argument: the ring slot of an energy exchange)
 };
 
 // Per-tile energy partials -> E = c1 E_s + c2 E_b (tet_spheres_cuda.cu:191), one workgroup of T threads, fixed
@@ -804,7 +805,9 @@ __device__ __forceinline__ void energy_reduce(const FinishArgs &a, double *red)
         a.terms[0] = red[0];
         a.terms[1] = red[T];
         const float c1 = a.coef ? a.coef[0] : a.c1, c2 = a.coef ? a.coef[1] : a.c2;
-        a.energy[0] = float(double(c1) * red[0] + double(c2) * red[T]);
+        const float e = float(double(c1) * red[0] + double(c2) * red[T]);
+        a.energy[0] = e;
+        if (a.energy_copy) a.energy_copy[0] = e;
     }
 }
 
@@ -1133,6 +1136,7 @@ hipError_t make_recipe(const EvalArgs &e, LaunchRecipe &r)
     f.coef = e.coef;
     f.energy = e.energy;
     f.terms = e.terms;
+    f.energy_copy = nullptr;
     if (f.n_finish > 0) {
         // one vertex per thread: the per-vertex chain off[k] -> rows -> store is pure latency, so expose all of it
         r.finish_fn = reinterpret_cast<const void *>(&finish_kernel);
@@ -1226,14 +1230,19 @@ hipError_t eval_graph_create(const EvalArgs &e, EvalGraph **out)
     return hipSuccess;
 }
 
-hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream)
+hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream, float *energy_copy)
 {
     hipError_t err;
-    if (g->r.k.c1 != c1 || g->r.k.c2 != c2 || g->r.f.c1 != c1 || g->r.f.c2 != c2) {
+    const bool coef = g->r.k.c1 != c1 || g->r.k.c2 != c2 || g->r.f.c1 != c1 || g->r.f.c2 != c2;
+    if (coef) {
         set_coefficients(g->r.k, c1, c2);
         g->r.f.c1 = c1;
         g->r.f.c2 = c2;
         if (g->tile_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile_node, &g->tile_p)) != hipSuccess) return err;
+    }
+    if (coef || g->r.f.energy_copy != energy_copy) {   // (the copy's address is an argument of the finish node, like the coefficients)
+        if (energy_copy && (!g->finish_node || !g->r.f.energy)) return hipErrorInvalidValue;   // (no node reduces the energy in this graph)
+        g->r.f.energy_copy = energy_copy;
         if (g->finish_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish_node, &g->finish_p)) != hipSuccess) return err;
     }
     return hipGraphLaunch(g->exec, stream);

@@ -129,8 +129,11 @@ inline uint32_t token_record(uint32_t token, uint32_t rec_base) { return (token 
 // One 16-byte load per lane and pair instead of two 8-byte loads: the same bytes in half the requests (a CU's ingest rate is
 // requests in flight / latency, tools/ubench_ingest.hip: 13.2 against 11.4 bytes per cycle and CU with two workgroups streaming).
 // Byte ranges of planes, row table and rest positions inside the blob are the same in both layouts.
+// Measured (round 6, tools/ab_variants.py base pair16, same box): tile kernel 512 x kuhn19 0.3688 -> 0.3639 ms, a.veg x 952 0.4102 ->
+// 0.3974 ms, bit-identical results.  (-DTSAMD_PAIRED_PLANES=0 builds the plane-after-plane image of rounds 1-5 for an A/B: the
+// one laboratory hook in the product sources, a build-time layout constant; tools/lab_variants.py `unpaired`.)
 #ifndef TSAMD_PAIRED_PLANES
-#define TSAMD_PAIRED_PLANES 0
+#define TSAMD_PAIRED_PLANES 1
 #endif
 TSAMD_HOST_DEVICE constexpr bool planes_paired(int spt) { return TSAMD_PAIRED_PLANES != 0 && (spt == 2 || spt == 4); }
 TSAMD_HOST_DEVICE constexpr bool plane_has_partner(int q, int n_planes) { return q != 12 && q != 13 && (q | 1) < n_planes; }

@@ -93,13 +93,17 @@ class GraphedSmoothnessBarrier:
         except Exception:
             pass
 
-    def evaluate(self, c1: float, c2: float, order: int):
+    def evaluate(self, c1: float, c2: float, order: int, energy_copy: torch.Tensor | None = None):
         """Replay the fused evaluation with these coefficients; returns the static ``(energy, grad)`` buffers
-        (``grad`` already multiplied by ``grad_scale``)."""
+        (``grad`` already multiplied by ``grad_scale``).  ``energy_copy``: a one-element float32 device tensor that receives
+        the energy as well (a per-launch argument of the replay: an energy exchange's ring slot, ``tsamd_graph_launch_to``)."""
         g = self._graphs.get(order)
         if g is None:
             g = self._graphs[order] = self._create(order)
-        _capi.check(_lib.tsamd_graph_launch(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device)))
+        if energy_copy is None:
+            _capi.check(_lib.tsamd_graph_launch(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device)))
+        else:
+            _capi.check(_lib.tsamd_graph_launch_to(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device), energy_copy.data_ptr()))
         return self.energy, self.grad
 
     def step(self, it: int, c1: float | None = None, c2: float | None = None):

@@ -70,6 +70,24 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
         multiplier = math.pow(2, abs(math.sin(min(it / 300.0 / 4 * 0.5 * math.pi, 0.5 * math.pi))) * 4)
         return smooth_coeff * multiplier, barrier_coeff * multiplier
 
+    def evaluate_direct(self, x, it, c1, c2, energy_copy=None):
+        """``graph=True`` only, not in the reference: the evaluation WITHOUT an autograd node -- one replay, returns
+        ``(energy, grad, still_valid)``: the replay's static device buffers (``grad`` = dE/dx, upstream gradient 1) and a callable
+        that says whether they still hold THIS evaluation (the next one overwrites them).  For callers that apply the gradient
+        themselves (tssplat_amd.sharding: ``JobWideEnergy.backward``); ``energy_copy`` as in ``GraphedSmoothnessBarrier.evaluate``.
+        None when ``x`` cannot be replayed (not this module's device / dtype / size)."""
+        if not (self.graph and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == self.tet_sp.n3
+                and x.device == self.tet_sp.device):
+            return None
+        from .graphed import GraphedSmoothnessBarrier
+        gr = self._graphed
+        if gr is None or gr.x.data_ptr() != x.data_ptr() or gr.x.shape != x.shape:
+            gr = self._graphed = GraphedSmoothnessBarrier(self, x.detach())
+        order = 4 if it > self.FLAGS.increase_order_iter else 2
+        energy, grad = gr.evaluate(c1, c2, order, energy_copy)
+        ticket = gr.ticket = gr.ticket + 1                    # (shared with the autograd nodes' counter: a pending backward() of theirs notices)
+        return energy, grad, (lambda: gr.ticket == ticket)
+
     def forward(self, x, it, c1, c2):
         order = 4 if it > self.FLAGS.increase_order_iter else 2      # smooth_barrier.py:61-63
         if not torch.is_grad_enabled():

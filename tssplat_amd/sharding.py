@@ -208,6 +208,7 @@ class OverlappedEnergyAllReduce:
             raise ValueError("depth must be >= 2")
         self.device, self.group, self.depth = torch.device(device), group, int(depth)
         self.ring = torch.zeros(self.depth, dtype=torch.float32, device=self.device)
+        self._slots = [self.ring[s:s + 1] for s in range(self.depth)]
         self._cuda = self.device.type == "cuda"
         self._side = torch.cuda.Stream(self.device) if self._cuda else None
         self._events = [torch.cuda.Event() for _ in range(self.depth)] if self._cuda else None
@@ -223,21 +224,24 @@ class OverlappedEnergyAllReduce:
 
     # ---- helper thread ----
     def _worker(self) -> None:
+        # What this thread does per collective while it holds the interpreter lock is what the training thread loses: the
+        # process group's own allreduce (one pybind call that releases the lock) instead of dist.all_reduce (argument checks,
+        # two logging decorators), the side stream made current ONCE for the thread, the slot views cut beforehand.
+        pg = self.group if self.group is not None else dist.distributed_c10d._get_default_group()
         if self._cuda:
             torch.cuda.set_device(self.device)
+            torch.cuda.set_stream(self._side)
+        bufs = [[self.ring[s:s + 1]] for s in range(self.depth)]
+        opts = dist.AllreduceOptions()
+        opts.reduceOp = dist.ReduceOp.SUM
         while True:
-            item = self._q.get()
-            if item is None:
+            s = self._q.get()
+            if s is None:
                 return
-            s = item
             try:
-                buf = self.ring[s:s + 1]
                 if self._cuda:
-                    with torch.cuda.stream(self._side):
-                        self._side.wait_event(self._events[s])
-                        self._works[s] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                else:
-                    self._works[s] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self._side.wait_event(self._events[s])
+                self._works[s] = pg.allreduce(bufs[s], opts)
                 self.collectives += 1
             except BaseException as exc:                      # noqa: BLE001  (handed to the reader)
                 self._error = exc
@@ -255,24 +259,34 @@ class OverlappedEnergyAllReduce:
             self._works[s] = None
 
     # ---- training thread ----
-    def submit(self, local_energy: torch.Tensor) -> int:
+    def reserve(self) -> tuple[int, torch.Tensor]:
+        """A ticket and its ring slot (a one-element view): the caller has the local energy written there ON THE CURRENT STREAM --
+        a replay does it itself, ``tsamd_graph_launch_to`` -- and then calls :meth:`commit`."""
         t = self._next
         self._next += 1
         s = t % self.depth
         if self._ticket_of_slot[s] >= 0:
             self._settle(s)                                   # (depth tickets old: long done; orders the overwrite behind it)
-        self.ring[s:s + 1].copy_(local_energy.detach().reshape(1), non_blocking=True)
         self._ticket_of_slot[s] = t
+        return t, self._slots[s]
+
+    def commit(self, ticket: int) -> None:
+        s = ticket % self.depth
         self._issued[s].clear()
         if not self._active:
             self._issued[s].set()
-            return t
+            return
         if self._cuda:
             self._events[s].record(torch.cuda.current_stream(self.device))
         if self._thread is None:
             self._thread = threading.Thread(target=self._worker, name="tssplat_amd-energy-allreduce", daemon=True)
             self._thread.start()
         self._q.put(s)
+
+    def submit(self, local_energy: torch.Tensor) -> int:
+        t, slot = self.reserve()
+        slot.copy_(local_energy.detach().reshape(1), non_blocking=True)
+        self.commit(t)
         return t
 
     def value(self, ticket: int) -> torch.Tensor:
@@ -305,6 +319,24 @@ class OverlappedEnergyAllReduce:
             pass
 
 
+class _AttachGradient(torch.autograd.Function):
+    """Forward value = the job-wide energy; backward = ``grad_output x`` the gradient an engine-free evaluation left in its
+    buffer (``still_valid()``: the buffer has not been overwritten by a newer evaluation)."""
+
+    @staticmethod
+    def forward(ctx, x, value, grad, still_valid):
+        ctx.grad, ctx.still_valid = grad, still_valid
+        return value.to(x.device, torch.float32).reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        if not ctx.still_valid():
+            raise RuntimeError("backward() of an energy whose gradient buffer a newer evaluation has overwritten: call backward() before "
+                               "the next forward, or build the module with graph=False")
+        g = ctx.grad
+        return g * go.detach().to(device=g.device, dtype=g.dtype), None, None, None
+
+
 def _plain(t):
     return t.as_subclass(torch.Tensor) if isinstance(t, torch.Tensor) and type(t) is not torch.Tensor else t
 
@@ -331,6 +363,20 @@ class JobWideEnergy(torch.Tensor):
         t._tsamd_reducer, t._tsamd_ticket, t._tsamd_resolved = reducer, ticket, None
         return t
 
+    @staticmethod
+    def wrap_direct(energy: torch.Tensor, reducer: "OverlappedEnergyAllReduce", ticket: int, x: torch.Tensor, grad: torch.Tensor,
+                    still_valid) -> "JobWideEnergy":
+        """The engine-free flavour (``graph=True``): the evaluation ran without an autograd node and left dE/dx in ``grad``.
+        ``backward()`` with no arguments adds it to ``x.grad`` itself -- what the autograd engine would do for this one-node
+        graph, minus the engine's round trip (40-50 us of host time per step, more than a 64-sphere share of the headline scene
+        takes on the GPU).  Anything else -- arithmetic, ``backward(gradient=...)``, ``inputs=`` -- first attaches the tensor to
+        ``x`` through an ordinary autograd node (:meth:`resolve`).  The tensor itself does NOT require grad: hand it to
+        ``torch.autograd.backward`` / ``grad`` as ``e.resolve()``."""
+        t = energy.detach().as_subclass(JobWideEnergy)
+        t._tsamd_reducer, t._tsamd_ticket, t._tsamd_resolved = reducer, ticket, None
+        t._tsamd_direct = (x, grad, still_valid)
+        return t
+
     def resolve(self) -> torch.Tensor:
         """The plain tensor: job-wide value (waits for the exchange), rank-local gradient."""
         red = getattr(self, "_tsamd_reducer", None)
@@ -339,14 +385,37 @@ class JobWideEnergy(torch.Tensor):
             if red is None:                                   # (a by-product such as ones_like(e): an ordinary tensor)
                 return plain
             if self._tsamd_resolved is None:
-                self._tsamd_resolved = _AddGlobal.apply(plain, red.value(self._tsamd_ticket))
+                direct = getattr(self, "_tsamd_direct", None)
+                if direct is not None and torch.is_grad_enabled():
+                    self._tsamd_resolved = _AttachGradient.apply(direct[0], red.value(self._tsamd_ticket), direct[1], direct[2])
+                elif direct is not None:
+                    return red.value(self._tsamd_ticket)      # (under no_grad: the value only; a later read attaches)
+                else:
+                    self._tsamd_resolved = _AddGlobal.apply(plain, red.value(self._tsamd_ticket))
             return self._tsamd_resolved
+
+    def _backward_direct(self) -> None:
+        x, grad, still_valid = self._tsamd_direct
+        if not still_valid():
+            raise RuntimeError("backward() of an energy whose gradient buffer a newer evaluation has overwritten: call backward() before "
+                               "the next forward, or build the module with graph=False")
+        with torch._C.DisableTorchFunctionSubclass(), torch.no_grad():
+            if x.grad is None:
+                x.grad = grad.clone()                         # (a fresh tensor: x.grad never aliases the replay's buffer)
+            else:
+                x.grad.add_(grad)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         name = getattr(func, "__name__", "")
         owner = getattr(func, "__self__", None)               # property getters arrive as `<getset_descriptor>.__get__`
+        if name == "backward" and args and getattr(args[0], "_tsamd_direct", None) is not None:
+            me = args[0]
+            if len(args) == 1 and not any(kwargs.get(k) for k in ("gradient", "inputs", "create_graph")):
+                return me._backward_direct()                  # d e / d e = 1: the gradient buffer goes to x.grad as it is
+            with torch._C.DisableTorchFunctionSubclass():
+                return me.resolve().backward(*args[1:], **kwargs)
         if name in cls._NO_VALUE or (name == "__get__" and getattr(owner, "__name__", "") in cls._NO_VALUE_GETTERS):
             with torch._C.DisableTorchFunctionSubclass():
                 return _plain(func(*args, **kwargs))
@@ -456,6 +525,23 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         cannot put the windows of the ranks out of step; at most ``max_pending`` reduced windows are kept for
         :meth:`reduced_energies` (the oldest are dropped with a warning: a loop that never asks for them does not
         accumulate device tensors)."""
+        if self.exchange == "overlap":
+            if self._overlap is None:
+                self._overlap = OverlappedEnergyAllReduce(x_local.device, self._energy_group, self.depth)
+            # Engine-free evaluation where nothing can tell the difference: a local evaluator that offers it (graph=True), a leaf
+            # parameter without hooks.  The replay writes the energy into the exchange's ring slot itself.
+            if (self.local is not None and torch.is_grad_enabled() and x_local.requires_grad and x_local.is_leaf
+                    and hasattr(self.local, "evaluate_direct") and not x_local._backward_hooks
+                    and not getattr(x_local, "_post_accumulate_grad_hooks", None)):
+                ticket, slot = self._overlap.reserve()
+                direct = self.local.evaluate_direct(x_local, it, c1, c2, energy_copy=slot)
+                if direct is not None:
+                    self._overlap.commit(ticket)
+                    return JobWideEnergy.wrap_direct(direct[0], self._overlap, ticket, x_local, direct[1], direct[2])
+                e_local = self.local(x_local, it, c1, c2)     # (this x cannot be replayed: the ordinary path into the same slot)
+                slot.copy_(e_local.detach().reshape(1), non_blocking=True)
+                self._overlap.commit(ticket)
+                return JobWideEnergy.wrap(e_local, self._overlap, ticket)
         if self.local is not None:
             e_local = self.local(x_local, it, c1, c2)
         else:                                   # more ranks than spheres: contribute zero
@@ -464,8 +550,6 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
             e_global = all_reduce_energy(e_local, self.group)
             return _AddGlobal.apply(e_local, e_global)
         if self.exchange == "overlap":
-            if self._overlap is None:
-                self._overlap = OverlappedEnergyAllReduce(e_local.device, self._energy_group, self.depth)
             ticket = self._overlap.submit(e_local)
             if not (torch.is_grad_enabled() and e_local.requires_grad):
                 return self._overlap.value(ticket)

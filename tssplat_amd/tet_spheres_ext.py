@@ -55,8 +55,9 @@ __all__ = ["TetSpheres", "forward", "backward", "random_x", "grad_limit"]
 
 _lib = _capi.load()          # fail loudly at import if the HIP library is absent
 CPU_ENERGY = os.environ.get("TSSPLAT_AMD_CPU_ENERGY", "0") == "1"   # read once: os.environ lookups are slow
-# default of TetSpheres(rebuild_dminv=None): stream the exactly rounded Dm^-1 planes (0) or rebuild it in registers (1)
-REBUILD_DMINV = os.environ.get("TSSPLAT_AMD_REBUILD_DMINV", "0") == "1"
+# TetSpheres(rebuild_dminv=None) = the library's choice (tsamd_options.rebuild_dminv 0: stream the exactly rounded Dm^-1 planes, except
+# for mid-size batches); TSSPLAT_AMD_REBUILD_DMINV=1 / 2 makes "always rebuild" / "always stream" the default instead
+REBUILD_DMINV = {"1": 1, "2": 2}.get(os.environ.get("TSSPLAT_AMD_REBUILD_DMINV", "0"), 0)
 print("initializing")         # tet_spheres.cpp:19 prints this at module import
 
 
@@ -117,8 +118,8 @@ class TetSpheres:
                                   debug_flags=int(debug_flags), lane_search_sweeps=int(lane_search_sweeps), slots_per_thread=slots_per_thread,
                                   # (the environment default only applies where it can; an explicit True that cannot be
                                   # honoured -- together with operator= -- is rejected by the library, not ignored)
-                                  rebuild_dminv=int(REBUILD_DMINV and operator is None) if rebuild_dminv is None
-                                  else int(bool(rebuild_dminv)))
+                                  rebuild_dminv=(REBUILD_DMINV if operator is None or REBUILD_DMINV != 1 else 0) if rebuild_dminv is None
+                                  else (1 if rebuild_dminv else 2))
         if isinstance(vertices, (str, os.PathLike)) and elements is None:
             if operator is not None:
                 raise TypeError("operator= needs the (vertices, elements) constructor")
