@@ -76,8 +76,9 @@ typedef struct tsamd_options {
                                 * CU) and 4 (max_threads <= 768): fewer, fatter waves, built-in operator only -- with lds_budget_bytes
                                 * up to 163840 these hold a whole ~3 k-tet sphere as ONE tile (no halo, no shared vertices).
                                 * Anything else is TSAMD_ERR_INVALID_ARGUMENT. */
-    int32_t rebuild_dminv;     /* 0 = auto: stream Dm^-1, except for plans of 513 ... 2 048 tiles built with default tiling options,
-                                * which rebuild it (a few rounds of workgroups: 256 x 3 k-tet spheres 24.8 -> 22.8 us per step);
+    int32_t rebuild_dminv;     /* 0 = auto: stream Dm^-1, except for plans of 513 ... 2 048 tiles built with default tiling options
+                                * whose tiles the rebuilt form does not shrink (a few rounds of workgroups of small spheres: 256 x 3 k-tet
+                                * spheres 24.8 -> 22.8 us per step), which rebuild it;
                                 * 2 = always stream; 1 = always rebuild:
                                 * keep rest positions (16 B per tile vertex) instead of the Dm^-1 planes (36 of the
                                 * 52 B per tile slot) and invert Dm per slot in fp32 registers: 45 % fewer bytes per

@@ -100,3 +100,48 @@ def with_const(mod):
 for graph in (False, True):
     m_cpp = SmoothnessBarrierEnergy(sc.rest, sc.tets, F, graph=graph)
     run(f"loss = a + energy(x, it, c1, c2); loss.backward()   graph={graph}, C++ node", with_const(m_cpp), N=4000)
+
+
+# ---- round 6: the sharded module with its own energy exchange, a single-rank RCCL group so that the helper thread
+#      and its collectives are real ----
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from tssplat_amd.sharding import ShardedSmoothnessBarrierEnergy
+vo = sc.sphere_vertex_offsets; to = np.arange(65) * (sc.n_tets // 64)
+def module_step(mod):
+    def f(i):
+        x.grad = None
+        it = i % 900
+        c1, c2 = mod.coeff_scheduler(it)
+        mod(x, it, c1, c2).backward()
+    return f
+for kw in (dict(graph=True), dict(graph=False), dict(graph=True, exchange="step"), dict(graph=True, exchange="window")):
+    mod = ShardedSmoothnessBarrierEnergy(sc.rest, sc.tets, F, vo, to, **kw)
+    run(f"ShardedSmoothnessBarrierEnergy({kw}) forward + backward()", module_step(mod), N=4000)
+    if getattr(mod, "_overlap", None) is not None:
+        mod._overlap.drain(); mod._overlap.close()
+# the pieces of the default module's step, host time only
+mod = ShardedSmoothnessBarrierEnergy(sc.rest, sc.tets, F, vo, to, graph=True)
+module_step(mod)(0)
+red, loc = mod._overlap, mod.local
+def piece(name, fn, N=4000):
+    for i in range(50): fn(i)
+    t = pc()
+    for i in range(N): fn(i)
+    print(f"    piece: {name:60s} {1e6 * (pc() - t) / N:6.1f} us")
+piece("coeff_scheduler", lambda i: mod.coeff_scheduler(i % 900))
+piece("reducer.reserve + commit (event record, queue)", lambda i: red.commit(red.reserve()[0]))
+slot = red.reserve()[1]; red.commit(red._next - 1)
+piece("local.evaluate_direct (replay, energy into a slot)", lambda i: loc.evaluate_direct(x, i % 900, 1e-4, 2e-4, energy_copy=slot))
+e = mod(x, 0, 1e-4, 2e-4)
+from tssplat_amd.sharding import JobWideEnergy
+piece("JobWideEnergy.wrap_direct", lambda i: JobWideEnergy.wrap_direct(loc._graphed.energy, red, 0, x, loc._graphed.grad, lambda: True))
+def bw(i):
+    x.grad = None
+    JobWideEnergy.wrap_direct(loc._graphed.energy, red, 0, x, loc._graphed.grad, lambda: True).backward()
+piece("x.grad = None; wrap_direct(...).backward()", bw)
+piece("module.__call__ alone (forward, no backward)", lambda i: mod(x, i % 900, 1e-4, 2e-4))
+torch.cuda.synchronize()
+red.drain(); red.close()
+dist.destroy_process_group()

@@ -42,6 +42,24 @@ VARIANTS = {
     "nostream": ("pricing: every tile reads tile 0's planes (L2 hits: the stream costs almost nothing, results wrong) at the production occupancy -- "
                  "the floor of a PERFECT next-tile prefetch with two workgroups per CU", [
         (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));")]),
+    "nostream32": ("pricing: tile t reads the planes of tile t mod 32 (2.6 MB: L2 / MALL hits spread over all channels -- `nostream` "
+                   "hammers ONE tile's 80 KB from every CU and is slower than the real stream) at the production occupancy", [
+        (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + a.tiles[tile & 31].blob_off);")]),
+    "onewg_nostream32": ("pricing: one workgroup per CU AND the planes from L2 (tile t mod 32) -- the floor of the LDS-DMA loader / consumer design", [
+        (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + a.tiles[tile & 31].blob_off);"),
+        (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
+        (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "onewg_exit_p1": ("pricing: one workgroup per CU, leave after pass 1 -- stage A of a LONE workgroup (stream + F); `onewg` minus this = the chain of passes a "
+                      "lone 12-wave workgroup needs behind it, i.e. what a loader / consumer workgroup's consumers would still have to do per tile", [
+        (K, "    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----",
+            "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
+        (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
+        (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "ntids": ("candidate: non-temporal loads for the other read-once data of a tile as well: vertex ids, destinations, row table", [
+        (K, "    const int32_t gv0 = as_global(a.gvid)[", "    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)["),
+        (K, "size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n    __builtin_amdgcn_sched_barrier(0);\n    tile_body", "size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);\n    __builtin_amdgcn_sched_barrier(0);\n    tile_body"),
+        (K, "        if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];", "        if (64 * vb0 + lane < td.n_verts) dst_row = __builtin_nontemporal_load(&g_vdst[td.vert_off + 64 * vb0 + lane]);"),
+        (K, "    if (WITH_GRAD) row0 = g_rowtab[tid < 65 ? tid : 64];", "    if (WITH_GRAD) row0 = __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);")]),
     "onewg": ("pricing: ONE workgroup per CU (100 KiB of dynamic LDS requested per workgroup, same tiles, same kernel)", [
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
@@ -50,11 +68,16 @@ VARIANTS = {
         (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
-    "ntplanes": ("candidate: non-temporal loads for the planes (each is read once, by one CU)", [
-        (K, "            const VU2 t = *reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt);",
-            "            const VU2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt));"),
-        (K, "            const VF2 t = *reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt);",
-            "            const VF2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt));")]),
+    "rows8": ("candidate: per-vertex sums walk EIGHT rows per trip instead of four (a.veg's fullest vertices carry up to 56 rows: 7 dependent LDS round trips instead of 14)", [
+        (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];\n#pragma unroll\n                for (int u = 0; u < 4; ++u) {",
+            "            for (int r = 0; r < rows; r += 8) {\n                const LDS_AS float *f[8];\n#pragma unroll\n                for (int u = 0; u < 8; ++u) {"),
+        (K, "#pragma unroll\n                for (int u = 0; u < 4; ++u) {\n                    gx += f[u][0];",
+            "#pragma unroll\n                for (int u = 0; u < 8; ++u) {\n                    gx += f[u][0];")]),
+    "tplanes": ("the planes through ordinary (temporal) loads, as until round 6 (the product loads them non-temporally)", [
+        (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt); };"),
+        (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt); };"),
+        (K, "            const VU2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt));", "            const VU2 t = *reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt);"),
+        (K, "            const VF2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt));", "            const VF2 t = *reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt);")]),
     # ---- candidates ----
     "stagger": ("the second workgroup of every CU starts half a tile late (first 512 workgroups: 256-511 sleep ~2.7 us)", [
         (K, "    if (jb >= a.tiles_per_xcd || tile >= tile_end) return;\n",

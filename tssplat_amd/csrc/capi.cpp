@@ -230,9 +230,11 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
     }
     // Mid-size batches (rebuild_dminv = 0, "auto"): a plan of a few rounds of workgroups (more than the 512 the chip holds at once,
     // at most 2 048) neither hides a tile's stream behind thousands of others nor is it a single tile's latency -- there the 36 of 52
-    // bytes per slot that rebuild_dminv does not stream win: 256 x kuhn8 24.8 -> 22.8 us per step (64 x kuhn8, one round: 14.3 ->
-    // 14.7, stays streamed; the 21 M-tet scene: +15 %, stays streamed; profiles/r06_experiments.md).  Built-in operator, default
-    // lane layout and tiling options only; 1 / 2 force either form.
+    // bytes per slot that rebuild_dminv does not stream win, PROVIDED the rest positions it keeps in LDS instead do not shrink the
+    // tiles: 256 / 384 / 512 x kuhn8 (tiles = quarter spheres either way) 24.8 -> 22.8, 34.6 -> 32.6, 41.9 -> 40.5 us per step; 32 /
+    // 48 x kuhn19 (1.300 against 1.284 slots per tet) 36.0 -> 37.6, 48.1 -> 50.3: stay streamed, like one-round batches (64 x kuhn8
+    // 14.3 -> 14.7) and the 21 M-tet scene (+15 %) (profiles/r06_experiments.md).  Built-in operator, default lane layout and tiling
+    // options only; 1 / 2 force either form.
     if (opt.rebuild_dminv == 0 && !op && po.slots_per_lane == tsamd::kSlotsPerLane && opt.max_threads == 0 && opt.target_owned == 0 &&
         opt.lds_budget_bytes == 0 && h->plan.tiles.size() > 512 && h->plan.tiles.size() <= 2048) {
         tsamd::PlanOptions po3 = po;
@@ -244,7 +246,7 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
             rc3 = tsamd::build_plan(rest, n, tets, m, po3, alt, err3, op);
         } catch (const std::bad_alloc &) {
         }
-        if (rc3 == 0 && alt.tiles.size() <= 2048) h->plan = std::move(alt);
+        if (rc3 == 0 && alt.tiles.size() <= 2048 && double(alt.total_slots) <= 1.002 * double(h->plan.total_slots)) h->plan = std::move(alt);
     }
     if (!opt.host_only) {
         rc = to_device(h, opt.device);

@@ -337,8 +337,11 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     // SPT dwords, and only 4 bytes for SPT == 3, where clang would otherwise assume the 16 of a padded 3-vector)
     typedef VU PlaneU __attribute__((aligned(SPT == 3 ? 4 : 4 * SPT)));
     typedef VF PlaneF __attribute__((aligned(SPT == 3 ? 4 : 4 * SPT)));
-    auto plane_u = [&](int q) -> VU { return *reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt); };
-    auto plane_f = [&](int q) -> VF { return *reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt); };
+    // Non-temporal loads: a tile's planes are read once, by one CU -- kept out of the way of what IS re-read (positions shared with
+    // the neighbouring tiles, the staging rows the finish kernel reads back).  Round 6, three scenes, same box each: tile kernel
+    // -1.2 % (kuhn19), -1.3 % (a.veg), -1.7 % (Delaunay); finish kernel -5 % (round 1's kernel had measured +1.4 %).
+    auto plane_u = [&](int q) -> VU { return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt)); };
+    auto plane_f = [&](int q) -> VF { return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt)); };
     // Two planes that are always loaded together are ONE load of twice the width (plan.h: planes_paired): in the device image
     // of the blob planes q and q + 1 are interleaved per lane -- [plane q: SPT dwords | plane q + 1: SPT dwords] -- so the
     // default layout's thirteen 8-byte loads per lane become six 16-byte loads and one 8-byte load.
@@ -347,7 +350,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     typedef float VF2 __attribute__((ext_vector_type(2 * SPT)));
     auto pair_u = [&](int q, VU &lo, VU &hi) {
         if (kPaired) {
-            const VU2 t = *reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt);
+            const VU2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VU2 *>(pl + q * td.s_pad + 2 * SPT * lt));
 #pragma unroll
             for (int p = 0; p < SPT; ++p) lo[p] = t[p], hi[p] = t[SPT + p];
         } else {
@@ -356,7 +359,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     };
     auto pair_f = [&](int q, VF &lo, VF &hi) {
         if (kPaired) {
-            const VF2 t = *reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt);
+            const VF2 t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt));
 #pragma unroll
             for (int p = 0; p < SPT; ++p) lo[p] = t[p], hi[p] = t[SPT + p];
         } else {

@@ -60,14 +60,15 @@ class GraphedSmoothnessBarrier:
         # evaluations so far (a backward must belong to the latest one): a one-element CPU tensor so that the C++ autograd node
         # (csrc/torch_autograd.cpp) and GraphReplayFunc count on the same cell
         self.ticket_tensor = torch.zeros(1, dtype=torch.int64)
+        self._ticket_cell = self.ticket_tensor.numpy()      # (the same memory: a numpy scalar access costs 0.1 us, a tensor index 3 us)
 
     @property
     def ticket(self) -> int:
-        return int(self.ticket_tensor[0])
+        return int(self._ticket_cell[0])
 
     @ticket.setter
     def ticket(self, value: int) -> None:
-        self.ticket_tensor[0] = int(value)
+        self._ticket_cell[0] = value
 
     def graph_address(self, order: int) -> int:
         """Address of the library graph for ``order`` (created on first use) -- what the C++ autograd node launches."""
