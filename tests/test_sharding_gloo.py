@@ -198,9 +198,23 @@ def _overlap_worker(rank, world, port, out):
         rec["ef"], rec["g_full"] = float(ef), xf.grad.numpy().copy()
         rec["collectives"] = mod._overlap.collectives
         rec["range"] = (lo, hi)
-        out[rank] = rec
+        rec["cxx"] = mod._overlap._cxx is not None             # the helper thread of csrc/torch_exchange.cpp (the extension builds on CPU)
         mod._overlap.drain()
         mod._overlap.close()
+        # the Python helper thread (the fallback without the extension): same protocol, same values, on a group of its own
+        from tssplat_amd.sharding import OverlappedEnergyAllReduce
+        red = OverlappedEnergyAllReduce("cpu", dist.new_group(), depth=4, use_extension=False)
+        assert red._cxx is None
+        tickets = [red.submit(torch.tensor(float(rank + 1) * (k + 1))) for k in range(6)]
+        rec["py_values"] = [float(red.value(t)) for t in tickets[2:]]
+        try:
+            red.value(tickets[0])
+            rec["py_expired"] = False
+        except RuntimeError:
+            rec["py_expired"] = True
+        red.drain()
+        red.close()
+        out[rank] = rec
     finally:
         dist.destroy_process_group()
 
@@ -230,6 +244,9 @@ def test_overlapped_exchange_job_wide_values_and_local_gradients(world):
         assert abs(rec["nograd"] - E0) <= 3e-6 * abs(E0) and abs(rec["ef"] - E0) <= 3e-6 * abs(E0)
         assert np.abs(rec["g_full"] - g0).max() <= 1e-5 * np.abs(g0).max()
         assert rec["collectives"] == 9                                                   # one per call, read or not
+        assert rec["cxx"] is True
+        tri = world * (world + 1) / 2
+        assert rec["py_values"] == [tri * (k + 1) for k in range(2, 6)] and rec["py_expired"] is True
 
 
 def test_overlapped_exchange_single_process():

@@ -132,7 +132,7 @@ def piece(name, fn, N=4000):
     print(f"    piece: {name:60s} {1e6 * (pc() - t) / N:6.1f} us")
 piece("coeff_scheduler", lambda i: mod.coeff_scheduler(i % 900))
 piece("reducer.reserve + commit (event record, queue)", lambda i: red.commit(red.reserve()[0]))
-slot = red.reserve()[1]; red.commit(red._next - 1)
+_t, slot = red.reserve(); red.commit(_t)
 piece("local.evaluate_direct (replay, energy into a slot)", lambda i: loc.evaluate_direct(x, i % 900, 1e-4, 2e-4, energy_copy=slot))
 e = mod(x, 0, 1e-4, 2e-4)
 from tssplat_amd.sharding import JobWideEnergy

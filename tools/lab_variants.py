@@ -55,11 +55,12 @@ VARIANTS = {
             "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
-    "ntids": ("candidate: non-temporal loads for the other read-once data of a tile as well: vertex ids, destinations, row table", [
-        (K, "    const int32_t gv0 = as_global(a.gvid)[", "    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)["),
-        (K, "size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];\n    __builtin_amdgcn_sched_barrier(0);\n    tile_body", "size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);\n    __builtin_amdgcn_sched_barrier(0);\n    tile_body"),
-        (K, "        if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];", "        if (64 * vb0 + lane < td.n_verts) dst_row = __builtin_nontemporal_load(&g_vdst[td.vert_off + 64 * vb0 + lane]);"),
-        (K, "    if (WITH_GRAD) row0 = g_rowtab[tid < 65 ? tid : 64];", "    if (WITH_GRAD) row0 = __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);")]),
+    "tfinish": ("the finish kernel's loads temporal, as until round 6", [(K, "#define FIN_LOAD(p) __builtin_nontemporal_load(p)", "#define FIN_LOAD(p) (*(p))")]),
+    "tids": ("vertex ids, destinations and row table through ordinary (temporal) loads, as until round 6", [
+        (K, "    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);",
+            "    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];"),
+        (K, "dst_row = __builtin_nontemporal_load(&g_vdst[td.vert_off + 64 * vb0 + lane]);", "dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];"),
+        (K, "row0 = __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);", "row0 = g_rowtab[tid < 65 ? tid : 64];")]),
     "onewg": ("pricing: ONE workgroup per CU (100 KiB of dynamic LDS requested per workgroup, same tiles, same kernel)", [
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
@@ -68,11 +69,12 @@ VARIANTS = {
         (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
-    "rows8": ("candidate: per-vertex sums walk EIGHT rows per trip instead of four (a.veg's fullest vertices carry up to 56 rows: 7 dependent LDS round trips instead of 14)", [
-        (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];\n#pragma unroll\n                for (int u = 0; u < 4; ++u) {",
-            "            for (int r = 0; r < rows; r += 8) {\n                const LDS_AS float *f[8];\n#pragma unroll\n                for (int u = 0; u < 8; ++u) {"),
-        (K, "#pragma unroll\n                for (int u = 0; u < 4; ++u) {\n                    gx += f[u][0];",
-            "#pragma unroll\n                for (int u = 0; u < 8; ++u) {\n                    gx += f[u][0];")]),
+    "rows4": ("the per-vertex sums walk four rows per trip in every tile, as until round 6 (the product: eight where a tile's force array has more than 32 rows)", [
+        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = 64;")]),
+    "rows8": ("the per-vertex sums walk eight rows per trip in every tile", [
+        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = -1;")]),
+    "rows8_24": ("eight rows per trip in tiles with more than 24 rows", [
+        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = 24;")]),
     "tplanes": ("the planes through ordinary (temporal) loads, as until round 6 (the product loads them non-temporally)", [
         (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt); };"),
         (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt); };"),

@@ -158,6 +158,7 @@ def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
     import torch
     from torch.utils import cpp_extension as ce
     h = hashlib.sha256(open(src, "rb").read())
+    h.update(open(os.path.join(CSRC, "torch_exchange.cpp"), "rb").read())
     h.update(open(os.path.join(CSRC, "..", "..", "include", "tssplat_amd.h"), "rb").read())   # the entry-point types it hard-codes
     h.update(torch.__version__.encode())
     digest = h.hexdigest()
@@ -180,7 +181,9 @@ def _build_torch_ext_locked(src: str, stamp: str, digest: str, verbose: bool) ->
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
     cmd += [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include", f"-I{sysconfig.get_paths()['include']}"]
     tmp = f"{TORCH_EXT}.{os.getpid()}.tmp"
-    cmd += [src, "-o", tmp, f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_python", f"-Wl,-rpath,{libdir}"]
+    # (torch_exchange.cpp: the energy exchange's helper thread -- c10d and HIP events through torch's own wrappers)
+    cmd += [src, os.path.join(CSRC, "torch_exchange.cpp"), "-o", tmp, "-pthread", f"-L{libdir}", "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10",
+            "-lc10_hip", "-ltorch_python", f"-Wl,-rpath,{libdir}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -223,7 +223,11 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
             rc2 = tsamd::build_plan(rest, n, tets, m, po2, alt, err2, op);
         } catch (const std::bad_alloc &) {
         }
-        if (rc2 == 0 && alt.tiles.size() > h->plan.tiles.size() && alt.tiles.size() <= 2048) {
+        // ... where the smaller tiles do not cost more than 3 % of halo: a sphere of 3 k tets falls into quarters instead of thirds
+        // (1.167 against 1.138 slots per tet), a 22 k- or 41 k-tet sphere would pay 3-5 % more slots for nothing (48 x a.veg: 34.8 ->
+        // 42.4 us per step with the smaller tiles; profiles/r06_experiments.md)
+        if (rc2 == 0 && alt.tiles.size() > h->plan.tiles.size() && alt.tiles.size() <= 2048 &&
+            double(alt.total_slots) <= 1.03 * double(h->plan.total_slots)) {
             h->plan = std::move(alt);
             po = po2;
         }

@@ -22,6 +22,7 @@
 // per forward+backward: :154, :185, :257).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -281,6 +282,7 @@ struct KernelArgs {
 };
 
 constexpr uint32_t kXS = kRowTabBytes;   // LDS byte address of the staged positions (plan.h: LDS map of a tile)
+constexpr int kDeepRows = 32;   // tiles whose force array has more rows walk it eight rows per trip (tile_body: vertex_sums)
 constexpr uint32_t kZeroEntry = 4u * 66u;   // three zero dwords behind the 65 row starts: what a lane without an entry in a row reads
 
 // byte offset (16 v) of a corner's staged position from its 16-bit vertex field (low / high half of a plane dword)
@@ -424,7 +426,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
     // join of a divergent branch the compiler waits for EVERY load in flight, and pass 1 would start behind the neighbour planes
     // (it did, for the first build of this layout: aveg x 952 0.4430 -> 0.4259 ms once the branch was gone).
     uint32_t row0 = 0;
-    if (WITH_GRAD) row0 = g_rowtab[tid < 65 ? tid : 64];
+    if (WITH_GRAD) row0 = __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);
     __builtin_amdgcn_sched_barrier(0);
 
     // The smoothness coefficient is applied ONCE per vertex at the very end instead of nine times per slot:
@@ -665,7 +667,7 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
             vb0 = g4 + (top - wave);
         }
         int32_t dst_row = 0;  // where this lane's first vertex goes: fetched here, a whole phase ahead of its use
-        if (64 * vb0 + lane < td.n_verts) dst_row = g_vdst[td.vert_off + 64 * vb0 + lane];
+        if (64 * vb0 + lane < td.n_verts) dst_row = __builtin_nontemporal_load(&g_vdst[td.vert_off + 64 * vb0 + lane]);
         __syncthreads();   // all waves done with H and with the staged positions
         // ---- scatter the vertex forces: (f0, f1, f2, f3), f0 = -(f1 + f2 + f3), 12 bytes each ----
         STAGE_PRIORITY(3);
@@ -697,23 +699,34 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
             const uint32_t v12 = 12u * uint32_t(v);
             const int rows = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wid > 768u * uint32_t(vb)));
             float gx = 0.f, gy = 0.f, gz = 0.f;
-            // (four rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
-            // beyond the tile's last one are empty: width 0.  Branch-free: a lane beyond a row's width reads the three zero
-            // dwords behind the row table instead, so that the four rows' reads are in flight together.)
-            for (int r = 0; r < rows; r += 4) {
-                const LDS_AS float *f[4];
+            // (TRIP rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
+            // beyond the tile's last one are empty: width 0 (the row index stays below 64: TRIP divides 64).  Branch-free: a lane
+            // beyond a row's width reads the three zero dwords behind the row table instead, so that a trip's reads are in flight
+            // together.)
+            auto walk = [&](auto trip) {
+                constexpr int TRIP = decltype(trip)::value;
+                for (int r = 0; r < rows; r += TRIP) {
+                    const LDS_AS float *f[TRIP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
-                    f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
-                }
+                    for (int u = 0; u < TRIP; ++u) {
+                        const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
+                        f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    gx += f[u][0];
-                    gy += f[u][1];
-                    gz += f[u][2];
+                    for (int u = 0; u < TRIP; ++u) {
+                        gx += f[u][0];
+                        gy += f[u][1];
+                        gz += f[u][2];
+                    }
                 }
-            }
+            };
+            // Four rows per trip where vertices meet few slots (a lattice tile: <= 24 rows), eight where the fullest carry many (a
+            // TetWild mesh: up to 56 rows -- 7 dependent LDS round trips instead of 14 at the very end of the tile).  Round 6, eight
+            // everywhere: a.veg x 952 -4.6 %, 512 x kuhn19 +3 %, Delaunay +0.8 %; hence by the tile's own depth (wave-uniform).
+            if (td.n_rows > kDeepRows)
+                walk(std::integral_constant<int, 8>());
+            else
+                walk(std::integral_constant<int, 4>());
             if (v < td.n_verts) {
                 const bool excl = row >= 0;
                 GLOBAL_AS float *dst = (excl ? g_grad : g_stage) + size_t(excl ? row : ~row) * 3;
@@ -749,7 +762,9 @@ __global__ __launch_bounds__(BLOCK, WPE) void tile_energy_kernel(const KernelArg
     // address needs only the tile number and a kernel argument (vertex ids sit at tile * vert_stride, plan.cpp), so it is
     // requested HERE, before the tile descriptor is even asked for: the chain is two memory latencies instead of three.
     // Entries beyond n_verts name vertex 0 and are never used.
-    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];
+    // (non-temporal, like every read-once array of a tile -- planes, ids, destinations, row table: what they would evict is what IS
+    // re-read, the positions shared with neighbouring tiles and the staging rows; round 6: a.veg x 952 tile kernel -6 %, finish -8 %)
+    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);
     __builtin_amdgcn_sched_barrier(0);
     tile_body<WITH_GRAD, WEIGHTED, REBUILD, SPT>(a, tile, gv0);
 }
@@ -824,6 +839,8 @@ __global__ __launch_bounds__(1024) void energy_reduce_kernel(const FinishArgs a)
 // Workgroup 0 reduces the energy partials (when asked to) while the others sum, for every vertex touched by
 // several tiles, its staged partial gradients in plan order (deterministic): one launch, and the 8 us of the
 // single-workgroup reduction hide behind the vertex work.
+// Everything the finish kernel reads is read for the last time (the staging rows) or once per evaluation (the lists): non-temporal.
+#define FIN_LOAD(p) __builtin_nontemporal_load(p)
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
 {
     __shared__ double red[2 * 256];
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
     const int64_t stride = int64_t(gridDim.x - 1) * 256;
     for (int64_t k = int64_t(blockIdx.x - 1) * 256 + tid; k < a.n_finish; k += stride) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
-        const int32_t e0 = a.fin_off[k], e1 = a.fin_off[k + 1];   // consecutive rows, tile order
+        const int32_t e0 = FIN_LOAD(&a.fin_off[k]), e1 = FIN_LOAD(&a.fin_off[k + 1]);   // consecutive rows, tile order
         // the first four rows go out together (most shared vertices have 2-4 copies): one memory latency instead of one
         // per row; rows beyond the vertex's own are re-reads of its last row and are not added.  Finish kernel 0.037 ->
         // 0.031 ms on the 512-sphere scene (2 / 3 / 8 rows: 0.034 / 0.031 / 0.031); same order of additions.
@@ -849,7 +866,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
                 // (a vertex no tet references is in the list with zero rows: e1 - 1 may be -1 -- read row 0, add nothing)
                 const int32_t e = e0 + j < e1 ? e0 + j : (e1 > 0 ? e1 - 1 : 0);
                 const float *p = a.stage + size_t(e) * 3;
-                r[j] = make_float3(p[0], p[1], p[2]);
+                r[j] = make_float3(FIN_LOAD(p), FIN_LOAD(p + 1), FIN_LOAD(p + 2));
             }
 #pragma unroll
             for (int j = 0; j < kRowsAhead; ++j)
@@ -861,11 +878,11 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
         }
         for (int32_t e = e0 + kRowsAhead; e < e1; ++e) {
             const float *r = a.stage + size_t(e) * 3;
-            gx += r[0];
-            gy += r[1];
-            gz += r[2];
+            gx += FIN_LOAD(r);
+            gy += FIN_LOAD(r + 1);
+            gz += FIN_LOAD(r + 2);
         }
-        float *g = a.grad + size_t(a.fin_vid[k]) * 3;
+        float *g = a.grad + size_t(FIN_LOAD(&a.fin_vid[k])) * 3;
         g[0] = gx * gscale;
         g[1] = gy * gscale;
         g[2] = gz * gscale;

@@ -113,8 +113,11 @@ at::Tensor energy_eval(const at::Tensor &x, int64_t handle, double c1, double c2
 
 }  // namespace
 
+void bind_energy_exchange(py::module &m);   // torch_exchange.cpp: the multi-GPU energy exchange's helper thread
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    bind_energy_exchange(m);
     m.def("set_entry_points", &set_entry_points, "addresses of tsamd_graph_launch, tsamd_forward_backward, tsamd_last_error");
     m.def("energy_replay", &energy_replay, "HIP-graph replay of the fused evaluation behind a C++ autograd node");
     m.def("energy_eval", &energy_eval, "eager fused evaluation behind a C++ autograd node");

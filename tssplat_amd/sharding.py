@@ -203,7 +203,7 @@ class OverlappedEnergyAllReduce:
     With one rank or no initialised process group the collective is the identity; everything else runs unchanged.
     """
 
-    def __init__(self, device, group=None, depth: int = 256):
+    def __init__(self, device, group=None, depth: int = 256, use_extension: bool = True):
         if depth < 2:
             raise ValueError("depth must be >= 2")
         self.device, self.group, self.depth = torch.device(device), group, int(depth)
@@ -220,9 +220,25 @@ class OverlappedEnergyAllReduce:
         self._thread: threading.Thread | None = None
         self._error: BaseException | None = None
         self._active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= 1
-        self.collectives = 0
+        self._collectives = 0
+        # The helper thread lives in the in-tree C++ extension when that is there (csrc/torch_exchange.cpp: same protocol, a
+        # std::thread, c10d called without the interpreter); the Python thread below is the fallback.  A Python helper competes
+        # with the training thread for the interpreter lock: 45 us of a 64 us step on the MI355X box (tools/host_overhead.py).
+        self._cxx = None
+        if use_extension:
+            from . import _capi
+            ext = _capi.autograd_ext()
+            if ext is not None and hasattr(ext, "EnergyExchange"):
+                pg = None
+                if self._active:
+                    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+                self._cxx = ext.EnergyExchange(self.ring, pg)
 
-    # ---- helper thread ----
+    @property
+    def collectives(self) -> int:
+        return int(self._cxx.collectives) if self._cxx is not None else self._collectives
+
+    # ---- helper thread (fallback) ----
     def _worker(self) -> None:
         # What this thread does per collective while it holds the interpreter lock is what the training thread loses: the
         # process group's own allreduce (one pybind call that releases the lock) instead of dist.all_reduce (argument checks,
@@ -242,7 +258,7 @@ class OverlappedEnergyAllReduce:
                 if self._cuda:
                     self._side.wait_event(self._events[s])
                 self._works[s] = pg.allreduce(bufs[s], opts)
-                self.collectives += 1
+                self._collectives += 1
             except BaseException as exc:                      # noqa: BLE001  (handed to the reader)
                 self._error = exc
             finally:
@@ -262,6 +278,8 @@ class OverlappedEnergyAllReduce:
     def reserve(self) -> tuple[int, torch.Tensor]:
         """A ticket and its ring slot (a one-element view): the caller has the local energy written there ON THE CURRENT STREAM --
         a replay does it itself, ``tsamd_graph_launch_to`` -- and then calls :meth:`commit`."""
+        if self._cxx is not None:
+            return self._cxx.reserve()
         t = self._next
         self._next += 1
         s = t % self.depth
@@ -271,6 +289,8 @@ class OverlappedEnergyAllReduce:
         return t, self._slots[s]
 
     def commit(self, ticket: int) -> None:
+        if self._cxx is not None:
+            return self._cxx.commit(ticket)
         s = ticket % self.depth
         self._issued[s].clear()
         if not self._active:
@@ -291,6 +311,8 @@ class OverlappedEnergyAllReduce:
 
     def value(self, ticket: int) -> torch.Tensor:
         """Job-wide energy of ``ticket`` (0-dim, a fresh tensor)."""
+        if self._cxx is not None:
+            return self._cxx.value(ticket)
         if not 0 <= ticket < self._next:
             raise ValueError(f"unknown ticket {ticket}")
         s = ticket % self.depth
@@ -302,11 +324,15 @@ class OverlappedEnergyAllReduce:
 
     def drain(self) -> None:
         """Every collective submitted so far has been issued and the current stream is ordered behind all of them."""
+        if self._cxx is not None:
+            return self._cxx.drain()
         for s in range(self.depth):
             if self._ticket_of_slot[s] >= 0:
                 self._settle(s)
 
     def close(self) -> None:
+        if self._cxx is not None:
+            self._cxx.close()
         if self._thread is not None:
             self._q.put(None)
             self._thread.join(timeout=10)
