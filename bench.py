@@ -80,6 +80,8 @@ def parse(argv=None):
                    help="spheres of the SAME scene (the first K, same seeds) the CPU baseline is timed on; 0 = the whole scene "
                         "up to ~2.7 M tets (64 x kuhn19, all of 64/256 x kuhn8)")
     p.add_argument("--cpu-threads", type=int, default=0, help="torch threads of the CPU baseline; 0 = min(16, host cores)")
+    p.add_argument("--module-every", type=int, default=1,
+                   help="--launch module: ShardedSmoothnessBarrierEnergy(every=N) -- one energy all-reduce per N steps (1 = every step)")
     p.add_argument("--force-collective", action="store_true",
                    help="N = 1 only: create a single-rank process group and issue the per-step energy exchange exactly as the "
                         "N > 1 path does, so that its host cost is inside the timed loop (scaling model, tools/scaling_model.py)")
@@ -384,7 +386,8 @@ def _run_rank(args, stdout_fd: int) -> None:
         # (rank 0 of 1 for the partition) while its energy exchange runs over the job's process group.
         energy.graph = graphed is not None
         sharded = ShardedSmoothnessBarrierEnergy(np.zeros((n_local, 3), np.float32), np.zeros((0, 4), np.int32), Flags, [0, n_local], [0, 0],
-                                                 rank=0, world_size=1, local_factory=lambda v, f, F: energy, exchange="overlap")
+                                                 rank=0, world_size=1, local_factory=lambda v, f, F: energy, exchange="overlap",
+                                                 every=max(1, args.module_every))
 
     def step_module(i):
         x.grad = None
@@ -439,7 +442,8 @@ def _run_rank(args, stdout_fd: int) -> None:
         if reducer is not None:
             reducer.flush()                 # the last (partial) window's collective is issued inside the timed region
         if sharded is not None and sharded._overlap is not None:
-            sharded._overlap.drain()        # every step's collective issued and completed inside the timed region
+            sharded.flush_exchange()        # (every > 1: the last, partial window)
+            sharded._overlap.drain()        # every collective issued and completed inside the timed region
         fence()
         el = time.perf_counter() - t0
         timed.local = el
@@ -474,7 +478,7 @@ def _run_rank(args, stdout_fd: int) -> None:
         # the module's own exchange: the value of the LAST step's JobWideEnergy (read now, long after the step) against the sum of
         # the rank-local energies of that step
         from tssplat_amd.sharding import JobWideEnergy
-        assert isinstance(e_last, JobWideEnergy) and sharded._overlap.collectives >= (args.steps if use_coll else 0)
+        assert isinstance(e_last, JobWideEnergy) and sharded._overlap.collectives >= (args.steps // max(1, args.module_every) if use_coll else 0)
         e_loc = e_last.as_subclass(torch.Tensor).detach().clone().reshape(1)
         parts = [torch.zeros(1, device=dev) for _ in range(world)]
         if world > 1:
@@ -579,12 +583,13 @@ def _run_rank(args, stdout_fd: int) -> None:
                 "launch": {"graph": "HIP-graph replay of the fused evaluation (GraphedSmoothnessBarrier.step)",
                            "eager": "eager: SmoothnessBarrierEnergy + backward() through torch.autograd",
                            "graph-autograd": "SmoothnessBarrierEnergy(graph=True) + backward(): HIP-graph replay behind an autograd node",
-                           "module": "ShardedSmoothnessBarrierEnergy(graph=%s, exchange='overlap').forward + backward()" % (graphed is not None)}[launch_mode],
+                           "module": "ShardedSmoothnessBarrierEnergy(graph=%s, exchange='overlap', every=%d).forward + backward()"
+                                     % (graphed is not None, max(1, args.module_every))}[launch_mode],
                 "schedule": "coefficients follow coeff_scheduler(it) and change every step (replays update them as kernel-node arguments, no device traffic)",
                 "energy_exchange": (f"per-step local energies into a ring of {reducer.window} device slots, one all-reduce per window "
                                     f"({reducer.collectives} collectives so far, backend {dist.get_backend()}, {dist.get_world_size()} rank(s))"
                                     if reducer is not None else
-                                    (f"the module's own: one all-reduce per step issued by a helper thread on a side stream, the job-wide value waited for "
+                                    (f"the module's own: one all-reduce per {max(1, args.module_every)} step(s) issued by a helper thread on a side stream, the job-wide value waited for "
                                      f"when read ({sharded._overlap.collectives} collectives, "
                                      + (f"backend {dist.get_backend()}, {dist.get_world_size()} rank(s))" if use_coll else "no process group)"))
                                     if sharded is not None else "none (one rank, no process group)"),

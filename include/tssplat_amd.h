@@ -209,10 +209,14 @@ typedef struct tsamd_graph tsamd_graph;
 int tsamd_graph_create(tsamd_handle *h, const float *x_dev, const float *grad_out_dev, int order, float *energy_dev,
                        float *grad_dev, tsamd_graph **out);
 int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream);
-/* The same replay, with the energy ALSO written to energy_copy_dev (one float; NULL = tsamd_graph_launch): a per-launch argument
- * like the coefficients.  It is how an energy exchange across GPUs gets this launch's value into its own ring slot without a
- * copy on the stream (tssplat_amd/sharding.py: OverlappedEnergyAllReduce).  Requires a graph created with energy_dev. */
-int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev);
+/* The same replay with its outputs redirected for THIS launch (per-launch arguments of the graph's nodes, like the coefficients):
+ *   energy_copy_dev  the energy is ALSO written there (one float; NULL = not): how an energy exchange across GPUs gets a launch's
+ *                    value into its own ring slot without a copy on the stream (tssplat_amd/sharding.py: OverlappedEnergyAllReduce);
+ *                    requires a graph created with energy_dev;
+ *   grad_dev         the gradient goes THERE instead of the buffer the graph was created with ([n_vertices, 3] floats; NULL = the
+ *                    graph's own): a caller that hands every evaluation's gradient on (x.grad of a training loop) gets it in a
+ *                    fresh buffer without a device copy; requires a graph created with grad_dev. */
+int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev, float *grad_dev);
 void tsamd_graph_destroy(tsamd_graph *graph);
 
 /* n_iters optimisation steps as ONE HIP graph: per step the evaluation above (energy into energy_ring_dev[k], gradient into

@@ -998,6 +998,12 @@ def test_sharded_module_with_its_own_exchange_on_gpu():
     assert rec["config"]["launch"].startswith("ShardedSmoothnessBarrierEnergy(graph=True")
     assert "helper thread" in rec["config"]["energy_exchange"] and "nccl" in rec["config"]["energy_exchange"]
     assert rec["value"] > 0 and np.isfinite(rec["energy"])
+    # one collective per 16 steps: same check of the last value against the rank sum
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scene", "kuhn8", "--spheres", "16", "--launch", "module", "--force-collective",
+                        "--module-every", "16", "--steps", "40", "--warmup", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-3000:]
+    assert "every=16" in json.loads(lines[-1])["config"]["launch"]
 
 
 def test_sharded_module_value_and_gradient_on_gpu(ext):

@@ -284,7 +284,7 @@ class _OracleEnergyDirect(_OracleEnergy):
         self.ticket += 1
         self.direct_calls += 1
         t = self.ticket
-        return self.e_buf, self.g_buf, (lambda: self.ticket == t)
+        return self.e_buf, self.g_buf.clone(), (lambda: self.ticket == t)   # (a fresh gradient tensor per evaluation, like the replay's)
 
 
 def _direct_worker(rank, world, port, out):
@@ -301,12 +301,17 @@ def _direct_worker(rank, world, port, out):
         xl = torch.nn.Parameter(torch.from_numpy(x[lo:hi].copy()))
         e = mod(xl, 0, c1, c2)
         assert isinstance(e, JobWideEnergy) and not e.requires_grad and e._tsamd_direct is not None
-        e.backward()                                           # engine-free: the buffer goes to x.grad
+        e.backward()                                           # engine-free: the evaluation's gradient tensor goes to x.grad
         assert e._tsamd_resolved is None
         g1 = xl.grad.numpy().copy()
-        e.backward()                                           # a second call accumulates, as autograd would
+        try:
+            e.backward()                                       # the graph is gone (as after a backward() without retain_graph)
+            rec["twice"] = False
+        except RuntimeError as exc:
+            rec["twice"] = "already" in str(exc)
+        ea = mod(xl, 0, c1, c2)
+        ea.backward()                                          # x.grad is set: a further evaluation accumulates, as autograd would
         rec["g1"], rec["g2"] = g1, xl.grad.numpy().copy()
-        assert xl.grad.data_ptr() != mod.local.g_buf.data_ptr()
         rec["value"] = float(e)                                # read late: job-wide
         # trainer.py:115 shape: the value takes part in a loss -> attached through an ordinary node, scaled gradient
         xl.grad = None
@@ -354,8 +359,65 @@ def test_engine_free_backward_of_the_overlapped_module():
         assert np.abs(rec["g1"] - g0[lo:hi]).max() <= tol and np.abs(rec["g2"] - 2.0 * g0[lo:hi]).max() <= 2 * tol
         assert abs(rec["value"] - E0) <= 3e-6 * abs(E0)
         assert np.abs(rec["g_loss"] - 2.0 * g0[lo:hi]).max() <= 2 * tol
-        assert rec["stale"] is True and rec["hook_ran"] is True
+        assert rec["stale"] is True and rec["hook_ran"] is True and rec["twice"] is True
         assert np.abs(rec["g_hook"] - g0[lo:hi]).max() <= tol
+
+
+def _every_worker(rank, world, port, out):
+    """exchange="overlap" with every=4: one collective per four calls; values readable from the end of their window on."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rest, tets, vo, to, x = _scene()
+        rec = {}
+        for use_ext in (True, False):
+            mod = ShardedSmoothnessBarrierEnergy(rest, tets, _Flags, vo, to, local_factory=_OracleEnergy, depth=8, every=4)
+            lo, hi = mod.vertex_range
+            c1, c2 = mod.coeff_scheduler(0)
+            if not use_ext:                                    # the Python helper thread: same protocol
+                from tssplat_amd.sharding import OverlappedEnergyAllReduce
+                mod._overlap = OverlappedEnergyAllReduce("cpu", mod._energy_group, 8, use_extension=False, every=4)
+            kept = []
+            for k in range(6):
+                xl = torch.from_numpy(x[lo:hi] * (1.0 + 0.01 * k)).requires_grad_(True)
+                e = mod(xl, 0, c1, c2)
+                e.backward()
+                kept.append(e)
+                if k == 1:
+                    try:
+                        float(e)                               # its window (calls 0-3) has not gone out yet: loud, no deadlock
+                        early = False
+                    except RuntimeError as exc:
+                        early = "not on its way" in str(exc)
+            vals = [float(e) for e in kept[:4]]                # window 0 went out with call 3
+            coll_before = mod._overlap.collectives
+            mod.flush_exchange()                               # calls 4, 5: a partial window, sent on request (every rank)
+            vals += [float(e) for e in kept[4:]]
+            mod._overlap.drain()
+            rec[use_ext] = dict(early=early, vals=vals, coll=(coll_before, mod._overlap.collectives), cxx=mod._overlap._cxx is not None)
+            mod._overlap.close()
+        out[rank] = rec
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_one_collective_per_window():
+    from oracle import tet_energy_oracle as O
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_every_worker, args=(world, port, out), nprocs=world, join=True)
+    rest, tets, vo, to, x = _scene()
+    cache = O.prepare(rest, tets)
+    Es = [O.energy_and_grad((x * (1.0 + 0.01 * k)).astype(np.float32), cache, _Flags.smooth_eng_coeff, _Flags.barrier_coeff, 2)[0] for k in range(6)]
+    for rank in range(world):
+        for use_ext in (True, False):
+            r = out[rank][use_ext]
+            assert r["early"] is True and r["cxx"] is use_ext
+            assert r["coll"] == (1, 2)                                                   # six calls: one full window + the flushed rest
+            assert all(abs(v - E) <= 3e-6 * abs(E) for v, E in zip(r["vals"], Es)), (rank, use_ext, r["vals"], Es)
 
 
 def test_rejects_spheres_that_share_vertices():

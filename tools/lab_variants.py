@@ -55,7 +55,7 @@ VARIANTS = {
             "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
-    "tfinish": ("the finish kernel's loads temporal, as until round 6", [(K, "#define FIN_LOAD(p) __builtin_nontemporal_load(p)", "#define FIN_LOAD(p) (*(p))")]),
+    "ntfinish": ("the finish kernel's loads non-temporal (measured: finish kernel +50 %)", [(K, "#define FIN_LOAD(p) (*(p))", "#define FIN_LOAD(p) __builtin_nontemporal_load(p)")]),
     "tids": ("vertex ids, destinations and row table through ordinary (temporal) loads, as until round 6", [
         (K, "    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);",
             "    const int32_t gv0 = as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)];"),
@@ -69,12 +69,11 @@ VARIANTS = {
         (K, "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + td.blob_off);", "reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + (td.blob_off & 0));"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
-    "rows4": ("the per-vertex sums walk four rows per trip in every tile, as until round 6 (the product: eight where a tile's force array has more than 32 rows)", [
-        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = 64;")]),
-    "rows8": ("the per-vertex sums walk eight rows per trip in every tile", [
-        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = -1;")]),
-    "rows8_24": ("eight rows per trip in tiles with more than 24 rows", [
-        (K, "constexpr int kDeepRows = 32;", "constexpr int kDeepRows = 24;")]),
+    "rows8": ("candidate: per-vertex sums walk EIGHT rows per trip instead of four (a.veg's fullest vertices carry up to 56 rows: 7 dependent LDS round trips instead of 14)", [
+        (K, "            for (int r = 0; r < rows; r += 4) {\n                const LDS_AS float *f[4];\n#pragma unroll\n                for (int u = 0; u < 4; ++u) {",
+            "            for (int r = 0; r < rows; r += 8) {\n                const LDS_AS float *f[8];\n#pragma unroll\n                for (int u = 0; u < 8; ++u) {"),
+        (K, "#pragma unroll\n                for (int u = 0; u < 4; ++u) {\n                    gx += f[u][0];",
+            "#pragma unroll\n                for (int u = 0; u < 8; ++u) {\n                    gx += f[u][0];")]),
     "tplanes": ("the planes through ordinary (temporal) loads, as until round 6 (the product loads them non-temporally)", [
         (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneU *>(pl + q * td.s_pad + SPT * lt); };"),
         (K, "return __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt)); };", "return *reinterpret_cast<const GLOBAL_AS PlaneF *>(pl + q * td.s_pad + SPT * lt); };"),

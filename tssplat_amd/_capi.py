@@ -90,7 +90,7 @@ SIGNATURES = {
                                           C.c_void_p]),
     "tsamd_graph_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "tsamd_graph_launch": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p]),
-    "tsamd_graph_launch_to": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "tsamd_graph_launch_to": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tsamd_graph_destroy": (None, [C.c_void_p]),
     "tsamd_read_energy_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "tsamd_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

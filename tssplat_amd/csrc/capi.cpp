@@ -224,10 +224,12 @@ int create_common(const float *rest, int64_t n, const int32_t *tets, int64_t m, 
         } catch (const std::bad_alloc &) {
         }
         // ... where the smaller tiles do not cost more than 3 % of halo: a sphere of 3 k tets falls into quarters instead of thirds
-        // (1.167 against 1.138 slots per tet), a 22 k- or 41 k-tet sphere would pay 3-5 % more slots for nothing (48 x a.veg: 34.8 ->
-        // 42.4 us per step with the smaller tiles; profiles/r06_experiments.md)
+        // (1.167 against 1.138 slots per tet), a 22 k- or 41 k-tet sphere would pay 3-5 % more slots for nothing (profiles/r06_experiments.md)
+        // (48 x a.veg: 34.8 -> 42.4 us per step with the smaller tiles) -- unless the smaller tiles still fit the chip's ONE round of 512
+        // workgroups, where they are simply more parallelism: 8 / 16 x a.veg 17.0 -> 16.5, 21.9 -> 21.1 us, 8 x kuhn19 20.0 -> 19.3,
+        // 20 x delaunay3000 22.5 -> 21.3; 12 x kuhn19 (648 tiles) 22.3 -> 24.7: not taken
         if (rc2 == 0 && alt.tiles.size() > h->plan.tiles.size() && alt.tiles.size() <= 2048 &&
-            double(alt.total_slots) <= 1.03 * double(h->plan.total_slots)) {
+            (alt.tiles.size() <= 512 || double(alt.total_slots) <= 1.03 * double(h->plan.total_slots))) {
             h->plan = std::move(alt);
             po = po2;
         }
@@ -495,14 +497,15 @@ int tsamd_graph_launch(tsamd_graph *graph, float c1, float c2, void *stream)
     return TSAMD_OK;
 }
 
-int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev)
+int tsamd_graph_launch_to(tsamd_graph *graph, float c1, float c2, void *stream, float *energy_copy_dev, float *grad_dev)
 {
     if (!graph || !graph->g) return fail(TSAMD_ERR_INVALID_ARGUMENT, "graph is null");
     DeviceGuard g;
     TSAMD_HIP(g.enter(graph->device));
-    const hipError_t e = tsamd::eval_graph_launch(graph->g, c1, c2, static_cast<hipStream_t>(stream), energy_copy_dev);
-    if (e == hipErrorInvalidValue && energy_copy_dev)
-        return fail(TSAMD_ERR_INVALID_ARGUMENT, "this graph has no node that writes the energy (created without energy_dev on an empty plan)");
+    const hipError_t e = tsamd::eval_graph_launch(graph->g, c1, c2, static_cast<hipStream_t>(stream), energy_copy_dev, grad_dev);
+    if (e == hipErrorInvalidValue && (energy_copy_dev || grad_dev))
+        return fail(TSAMD_ERR_INVALID_ARGUMENT, "this graph cannot redirect that output: it was created without energy_dev / without grad_dev "
+                                                "(no node of it computes the value)");
     TSAMD_HIP(e);
     return TSAMD_OK;
 }

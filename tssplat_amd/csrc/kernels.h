@@ -41,7 +41,7 @@ hipError_t launch_eval(const EvalArgs &a, hipStream_t stream, hipEvent_t *ev = n
 // The EvalArgs pointers (x, grad_out, energy, grad, plan data) are baked in; e.coef must be null.
 struct EvalGraph;
 hipError_t eval_graph_create(const EvalArgs &a, EvalGraph **out);
-hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream, float *energy_copy = nullptr);
+hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream, float *energy_copy = nullptr, float *grad = nullptr);
 void eval_graph_destroy(EvalGraph *g);
 // n_iters optimisation steps -- energy + gradient, then the AdamUniform update of x from that gradient -- as ONE graph: per
 // step a tile node, a finish node and the two optimiser nodes, chained; x is updated in place and read by the next step.

@@ -22,7 +22,6 @@
 // per forward+backward: :154, :185, :257).
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -282,7 +281,6 @@ struct KernelArgs {
 };
 
 constexpr uint32_t kXS = kRowTabBytes;   // LDS byte address of the staged positions (plan.h: LDS map of a tile)
-constexpr int kDeepRows = 32;   // tiles whose force array has more rows walk it eight rows per trip (tile_body: vertex_sums)
 constexpr uint32_t kZeroEntry = 4u * 66u;   // three zero dwords behind the 65 row starts: what a lane without an entry in a row reads
 
 // byte offset (16 v) of a corner's staged position from its 16-bit vertex field (low / high half of a plane dword)
@@ -699,34 +697,25 @@ __device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, i
             const uint32_t v12 = 12u * uint32_t(v);
             const int rows = __builtin_popcountll(__builtin_amdgcn_ballot_w64(wid > 768u * uint32_t(vb)));
             float gx = 0.f, gy = 0.f, gz = 0.f;
-            // (TRIP rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
-            // beyond the tile's last one are empty: width 0 (the row index stays below 64: TRIP divides 64).  Branch-free: a lane
-            // beyond a row's width reads the three zero dwords behind the row table instead, so that a trip's reads are in flight
-            // together.)
-            auto walk = [&](auto trip) {
-                constexpr int TRIP = decltype(trip)::value;
-                for (int r = 0; r < rows; r += TRIP) {
-                    const LDS_AS float *f[TRIP];
+            // (four rows per trip, unrolled by hand -- v_readlane is convergent, the compiler does not unroll around it; rows
+            // beyond the tile's last one are empty: width 0.  Branch-free: a lane beyond a row's width reads the three zero
+            // dwords behind the row table instead, so that the four rows' reads are in flight together.  Eight rows per trip --
+            // a.veg's fullest vertices carry 56 -- were measured in round 6: -4.6 % on a.veg before the read-once arrays went
+            // non-temporal, nothing after (0.3814 against 0.3820 ms), +0.3 % on the lattice: tools/lab_variants.py rows8.)
+            for (int r = 0; r < rows; r += 4) {
+                const LDS_AS float *f[4];
 #pragma unroll
-                    for (int u = 0; u < TRIP; ++u) {
-                        const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
-                        f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
-                    }
-#pragma unroll
-                    for (int u = 0; u < TRIP; ++u) {
-                        gx += f[u][0];
-                        gy += f[u][1];
-                        gz += f[u][2];
-                    }
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
+                    f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
                 }
-            };
-            // Four rows per trip where vertices meet few slots (a lattice tile: <= 24 rows), eight where the fullest carry many (a
-            // TetWild mesh: up to 56 rows -- 7 dependent LDS round trips instead of 14 at the very end of the tile).  Round 6, eight
-            // everywhere: a.veg x 952 -4.6 %, 512 x kuhn19 +3 %, Delaunay +0.8 %; hence by the tile's own depth (wave-uniform).
-            if (td.n_rows > kDeepRows)
-                walk(std::integral_constant<int, 8>());
-            else
-                walk(std::integral_constant<int, 4>());
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gx += f[u][0];
+                    gy += f[u][1];
+                    gz += f[u][2];
+                }
+            }
             if (v < td.n_verts) {
                 const bool excl = row >= 0;
                 GLOBAL_AS float *dst = (excl ? g_grad : g_stage) + size_t(excl ? row : ~row) * 3;
@@ -839,8 +828,10 @@ __global__ __launch_bounds__(1024) void energy_reduce_kernel(const FinishArgs a)
 // Workgroup 0 reduces the energy partials (when asked to) while the others sum, for every vertex touched by
 // several tiles, its staged partial gradients in plan order (deterministic): one launch, and the 8 us of the
 // single-workgroup reduction hide behind the vertex work.
-// Everything the finish kernel reads is read for the last time (the staging rows) or once per evaluation (the lists): non-temporal.
-#define FIN_LOAD(p) __builtin_nontemporal_load(p)
+// (Ordinary loads: non-temporal ones for the staging rows and lists -- read for the last time / once per evaluation -- were measured,
+// round 6: finish kernel 0.0269 -> 0.0409 ms on 512 x kuhn19, 0.0297 -> 0.0414 on a.veg x 952.  The rows are still in the memory-side
+// cache from the tile kernel's stores; a non-temporal read gives that up.)
+#define FIN_LOAD(p) (*(p))
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs a)
 {
     __shared__ double red[2 * 256];
@@ -1206,6 +1197,7 @@ struct EvalGraph {
     hipGraphNode_t tile_node = nullptr, finish_node = nullptr;
     hipKernelNodeParams tile_p, finish_p;
     void *tile_argv[1], *finish_argv[1];
+    float *own_grad = nullptr;   // the gradient buffer the graph was created with (a launch may name another one)
 };
 
 hipError_t eval_graph_create(const EvalArgs &e, EvalGraph **out)
@@ -1213,6 +1205,7 @@ hipError_t eval_graph_create(const EvalArgs &e, EvalGraph **out)
     *out = nullptr;
     EvalGraph *g = new EvalGraph();
     hipError_t err = make_recipe(e, g->r);
+    g->own_grad = e.grad;
     auto fail = [&](hipError_t code) {
         eval_graph_destroy(g);
         return code;
@@ -1250,19 +1243,25 @@ hipError_t eval_graph_create(const EvalArgs &e, EvalGraph **out)
     return hipSuccess;
 }
 
-hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream, float *energy_copy)
+hipError_t eval_graph_launch(EvalGraph *g, float c1, float c2, hipStream_t stream, float *energy_copy, float *grad)
 {
     hipError_t err;
     const bool coef = g->r.k.c1 != c1 || g->r.k.c2 != c2 || g->r.f.c1 != c1 || g->r.f.c2 != c2;
-    if (coef) {
+    // (the gradient's address is an argument of both nodes, the energy copy's of the finish node -- per-launch, like the coefficients)
+    if (!grad) grad = g->own_grad;
+    if (grad != g->r.f.grad && !g->own_grad) return hipErrorInvalidValue;   // (a graph created without a gradient has no backward kernels)
+    const bool moved = grad != g->r.f.grad;
+    if (coef || moved) {
         set_coefficients(g->r.k, c1, c2);
         g->r.f.c1 = c1;
         g->r.f.c2 = c2;
+        g->r.k.grad = grad;
         if (g->tile_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->tile_node, &g->tile_p)) != hipSuccess) return err;
     }
-    if (coef || g->r.f.energy_copy != energy_copy) {   // (the copy's address is an argument of the finish node, like the coefficients)
+    if (coef || moved || g->r.f.energy_copy != energy_copy) {
         if (energy_copy && (!g->finish_node || !g->r.f.energy)) return hipErrorInvalidValue;   // (no node reduces the energy in this graph)
         g->r.f.energy_copy = energy_copy;
+        g->r.f.grad = grad;
         if (g->finish_node && (err = hipGraphExecKernelNodeSetParams(g->exec, g->finish_node, &g->finish_p)) != hipSuccess) return err;
     }
     return hipGraphLaunch(g->exec, stream);

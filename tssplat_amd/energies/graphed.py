@@ -94,18 +94,22 @@ class GraphedSmoothnessBarrier:
         except Exception:
             pass
 
-    def evaluate(self, c1: float, c2: float, order: int, energy_copy: torch.Tensor | None = None):
-        """Replay the fused evaluation with these coefficients; returns the static ``(energy, grad)`` buffers
-        (``grad`` already multiplied by ``grad_scale``).  ``energy_copy``: a one-element float32 device tensor that receives
-        the energy as well (a per-launch argument of the replay: an energy exchange's ring slot, ``tsamd_graph_launch_to``)."""
+    def evaluate(self, c1: float, c2: float, order: int, energy_copy: torch.Tensor | None = None, grad_out: torch.Tensor | None = None):
+        """Replay the fused evaluation with these coefficients; returns ``(energy, grad)``: the static energy buffer and the
+        gradient (already multiplied by ``grad_scale``) -- in the static buffer, or in ``grad_out`` when one is given (a contiguous
+        float32 tensor shaped like ``x``; a per-launch argument of the replay, ``tsamd_graph_launch_to``: the caller keeps that
+        tensor, no copy).  ``energy_copy``: a one-element float32 device tensor that receives the energy as well (an energy
+        exchange's ring slot)."""
         g = self._graphs.get(order)
         if g is None:
             g = self._graphs[order] = self._create(order)
-        if energy_copy is None:
+        if energy_copy is None and grad_out is None:
             _capi.check(_lib.tsamd_graph_launch(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device)))
-        else:
-            _capi.check(_lib.tsamd_graph_launch_to(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device), energy_copy.data_ptr()))
-        return self.energy, self.grad
+            return self.energy, self.grad
+        _capi.check(_lib.tsamd_graph_launch_to(g, c1, c2, tet_spheres_ext._stream_ptr(self.x.device),
+                                               None if energy_copy is None else energy_copy.data_ptr(),
+                                               None if grad_out is None else grad_out.data_ptr()))
+        return self.energy, (self.grad if grad_out is None else grad_out)
 
     def step(self, it: int, c1: float | None = None, c2: float | None = None):
         """One evaluation at iteration ``it``: coefficients from ``coeff_scheduler(it)`` unless given, order 4 after

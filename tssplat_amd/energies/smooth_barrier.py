@@ -18,6 +18,10 @@ from .. import tet_spheres_ext
 __all__ = ["SmoothnessBarrierFunc", "SmoothnessBarrierEnergy"]
 
 
+def _ALWAYS() -> bool:
+    return True
+
+
 class SmoothnessBarrierFunc(torch.autograd.Function):
     """autograd bridge: saves ``x`` only, constants ride on ctx (smooth_barrier.py:9-31).
 
@@ -72,10 +76,11 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
 
     def evaluate_direct(self, x, it, c1, c2, energy_copy=None):
         """``graph=True`` only, not in the reference: the evaluation WITHOUT an autograd node -- one replay, returns
-        ``(energy, grad, still_valid)``: the replay's static device buffers (``grad`` = dE/dx, upstream gradient 1) and a callable
-        that says whether they still hold THIS evaluation (the next one overwrites them).  For callers that apply the gradient
-        themselves (tssplat_amd.sharding: ``JobWideEnergy.backward``); ``energy_copy`` as in ``GraphedSmoothnessBarrier.evaluate``.
-        None when ``x`` cannot be replayed (not this module's device / dtype / size)."""
+        ``(energy, grad, still_valid)``: the replay's static energy buffer, dE/dx (upstream gradient 1) in a FRESH tensor the
+        replay wrote directly (the caller may keep it: no copy), and a callable that says whether ``grad`` still holds this
+        evaluation (always: it is the evaluation's own).  For callers that apply the gradient themselves (tssplat_amd.sharding:
+        ``JobWideEnergy.backward``); ``energy_copy`` as in ``GraphedSmoothnessBarrier.evaluate``.  None when ``x`` cannot be replayed
+        (not this module's device / dtype / size)."""
         if not (self.graph and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.numel() == self.tet_sp.n3
                 and x.device == self.tet_sp.device):
             return None
@@ -84,9 +89,9 @@ class SmoothnessBarrierEnergy(torch.nn.Module):
         if gr is None or gr.x.data_ptr() != x.data_ptr() or gr.x.shape != x.shape:
             gr = self._graphed = GraphedSmoothnessBarrier(self, x.detach())
         order = 4 if it > self.FLAGS.increase_order_iter else 2
-        energy, grad = gr.evaluate(c1, c2, order, energy_copy)
-        ticket = gr.ticket = gr.ticket + 1                    # (shared with the autograd nodes' counter: a pending backward() of theirs notices)
-        return energy, grad, (lambda: gr.ticket == ticket)
+        energy, grad = gr.evaluate(c1, c2, order, energy_copy, torch.empty_like(gr.x))
+        gr.ticket = gr.ticket + 1                             # (the autograd nodes' counter: a pending backward() of theirs sees a newer evaluation)
+        return energy, grad, _ALWAYS
 
     def forward(self, x, it, c1, c2):
         order = 4 if it > self.FLAGS.increase_order_iter else 2      # smooth_barrier.py:61-63

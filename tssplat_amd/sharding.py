@@ -196,17 +196,22 @@ class OverlappedEnergyAllReduce:
     rank) are spent next to the training thread, not in it.  ``value(ticket)`` waits -- host-side until the helper has
     issued the collective, stream-side for its completion -- and returns the job-wide energy.  Collectives are issued in
     ticket order by ONE thread, so every rank issues the same sequence as long as every rank submits the same sequence
-    (the rule of any collective) -- on ``group``, which must carry NOTHING else: the training thread's own collectives would
+    (the rule of any collective; ``every`` > 1: ONE collective per window of ``every`` evaluations, issued with the window's last one --
+    for steps so short that even an asynchronous collective per step shows on the GPU's timeline; a value is readable once its
+    window has gone out, a read before that raises) -- on ``group``, which must carry NOTHING else: the training thread's own collectives would
     interleave with the helper's in a different order on every rank (``ShardedSmoothnessBarrierEnergy`` creates a group for
     it).  A slot is re-used after ``depth`` tickets: older values have expired.
 
     With one rank or no initialised process group the collective is the identity; everything else runs unchanged.
     """
 
-    def __init__(self, device, group=None, depth: int = 256, use_extension: bool = True):
+    def __init__(self, device, group=None, depth: int = 256, use_extension: bool = True, every: int = 1):
         if depth < 2:
             raise ValueError("depth must be >= 2")
-        self.device, self.group, self.depth = torch.device(device), group, int(depth)
+        if every < 1 or depth % every or depth < 2 * every:
+            raise ValueError("`every` must divide the ring depth at least twice")
+        self.device, self.group, self.depth, self.every = torch.device(device), group, int(depth), int(every)
+        self._committed = self._issued_upto = 0
         self.ring = torch.zeros(self.depth, dtype=torch.float32, device=self.device)
         self._slots = [self.ring[s:s + 1] for s in range(self.depth)]
         self._cuda = self.device.type == "cuda"
@@ -214,6 +219,8 @@ class OverlappedEnergyAllReduce:
         self._events = [torch.cuda.Event() for _ in range(self.depth)] if self._cuda else None
         self._works: list = [None] * self.depth
         self._issued = [threading.Event() for _ in range(self.depth)]
+        for ev in self._issued:
+            ev.set()
         self._ticket_of_slot = [-1] * self.depth
         self._next = 0
         self._q: queue.SimpleQueue = queue.SimpleQueue()
@@ -232,7 +239,7 @@ class OverlappedEnergyAllReduce:
                 pg = None
                 if self._active:
                     pg = group if group is not None else dist.distributed_c10d._get_default_group()
-                self._cxx = ext.EnergyExchange(self.ring, pg)
+                self._cxx = ext.EnergyExchange(self.ring, pg, self.every)
 
     @property
     def collectives(self) -> int:
@@ -247,22 +254,25 @@ class OverlappedEnergyAllReduce:
         if self._cuda:
             torch.cuda.set_device(self.device)
             torch.cuda.set_stream(self._side)
-        bufs = [[self.ring[s:s + 1]] for s in range(self.depth)]
         opts = dist.AllreduceOptions()
         opts.reduceOp = dist.ReduceOp.SUM
         while True:
-            s = self._q.get()
-            if s is None:
+            item = self._q.get()
+            if item is None:
                 return
+            s, count = item
             try:
                 if self._cuda:
                     self._side.wait_event(self._events[s])
-                self._works[s] = pg.allreduce(bufs[s], opts)
+                w = pg.allreduce([self.ring[s:s + count]], opts)
+                for k in range(count):
+                    self._works[s + k] = w                    # (every slot of the window waits on the same handle)
                 self._collectives += 1
             except BaseException as exc:                      # noqa: BLE001  (handed to the reader)
                 self._error = exc
             finally:
-                self._issued[s].set()
+                for k in range(count):
+                    self._issued[s + k].set()
 
     def _settle(self, s: int) -> None:
         """The collective that last used slot ``s`` has been issued and the CURRENT stream is ordered behind its completion."""
@@ -289,19 +299,36 @@ class OverlappedEnergyAllReduce:
         return t, self._slots[s]
 
     def commit(self, ticket: int) -> None:
+        """Tickets are committed in the order they were reserved.  With ``every`` > 1 the collective covers the slots of a window
+        and goes out with the window's last ticket."""
         if self._cxx is not None:
             return self._cxx.commit(ticket)
-        s = ticket % self.depth
-        self._issued[s].clear()
+        if ticket != self._committed:
+            raise RuntimeError("tickets are committed in the order they were reserved")
+        self._committed += 1
+        if self._committed % self.every == 0:
+            self._issue(self._issued_upto, self._committed - self._issued_upto)
+
+    def flush(self) -> None:
+        """The all-reduce of the committed part of the current window now (a collective: every rank, at the same ticket)."""
+        if self._cxx is not None:
+            return self._cxx.flush()
+        if self._committed > self._issued_upto:
+            self._issue(self._issued_upto, self._committed - self._issued_upto)
+
+    def _issue(self, first: int, count: int) -> None:
+        self._issued_upto = first + count
         if not self._active:
-            self._issued[s].set()
             return
+        s0 = first % self.depth
+        for k in range(count):
+            self._issued[s0 + k].clear()
         if self._cuda:
-            self._events[s].record(torch.cuda.current_stream(self.device))
+            self._events[s0].record(torch.cuda.current_stream(self.device))
         if self._thread is None:
             self._thread = threading.Thread(target=self._worker, name="tssplat_amd-energy-allreduce", daemon=True)
             self._thread.start()
-        self._q.put(s)
+        self._q.put((s0, count))
 
     def submit(self, local_energy: torch.Tensor) -> int:
         t, slot = self.reserve()
@@ -319,6 +346,10 @@ class OverlappedEnergyAllReduce:
         if self._ticket_of_slot[s] != ticket:
             raise RuntimeError(f"the job-wide energy of evaluation {ticket} has expired: {self._next - ticket} evaluations ago, the ring keeps "
                                f"{self.depth} (read it sooner, or build the module with a larger `depth`)")
+        if ticket >= self._issued_upto:
+            raise RuntimeError(f"the job-wide energy of evaluation {ticket} is not on its way yet: with every = {self.every} the all-reduce of a "
+                               f"window is issued with its last evaluation ({self._issued_upto} evaluations are covered so far).  Read it later, "
+                               "call flush() on EVERY rank, or build the module with every = 1")
         self._settle(s)
         return self.ring[s].clone()
 
@@ -327,7 +358,7 @@ class OverlappedEnergyAllReduce:
         if self._cxx is not None:
             return self._cxx.drain()
         for s in range(self.depth):
-            if self._ticket_of_slot[s] >= 0:
+            if 0 <= self._ticket_of_slot[s] < self._issued_upto:
                 self._settle(s)
 
     def close(self) -> None:
@@ -412,6 +443,8 @@ class JobWideEnergy(torch.Tensor):
                 return plain
             if self._tsamd_resolved is None:
                 direct = getattr(self, "_tsamd_direct", None)
+                if direct is not None and direct[1] is None:
+                    return red.value(self._tsamd_ticket)      # (already back-propagated: the value is all that is left)
                 if direct is not None and torch.is_grad_enabled():
                     self._tsamd_resolved = _AttachGradient.apply(direct[0], red.value(self._tsamd_ticket), direct[1], direct[2])
                 elif direct is not None:
@@ -422,14 +455,18 @@ class JobWideEnergy(torch.Tensor):
 
     def _backward_direct(self) -> None:
         x, grad, still_valid = self._tsamd_direct
+        if grad is None:
+            raise RuntimeError("this energy has been back-propagated already and its gradient tensor handed to x.grad (the engine-free path "
+                               "keeps no graph): evaluate again, or use e.resolve().backward(retain_graph=True)")
         if not still_valid():
             raise RuntimeError("backward() of an energy whose gradient buffer a newer evaluation has overwritten: call backward() before "
                                "the next forward, or build the module with graph=False")
         with torch._C.DisableTorchFunctionSubclass(), torch.no_grad():
             if x.grad is None:
-                x.grad = grad.clone()                         # (a fresh tensor: x.grad never aliases the replay's buffer)
+                x.grad = grad                                 # (the evaluation's own tensor, written by the replay: handed over, not copied)
             else:
                 x.grad.add_(grad)
+        self._tsamd_direct = (x, None, still_valid)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -477,13 +514,13 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
     def __init__(self, tet_v, tet_f, FLAGS, sphere_vertex_offsets, sphere_tet_offsets, group=None,
                  rank: int | None = None, world_size: int | None = None,
                  local_factory: Callable | None = None, exchange: str = "overlap", window: int = 16, depth: int = 256,
-                 graph: bool = False, **local_kwargs):
+                 every: int = 1, graph: bool = False, **local_kwargs):
         super().__init__()
         if exchange not in ("overlap", "window", "step"):
             raise ValueError("exchange must be 'overlap' (one all-reduce per call issued off the training thread, the job-wide value "
                              "waited for when it is read), 'step' (the same all-reduce inside the call) or 'window' (rank-local "
                              "value; one collective per `window` steps, job-wide values from reduced_energies())")
-        self.exchange, self.window, self.depth = exchange, int(window), int(depth)
+        self.exchange, self.window, self.depth, self.every = exchange, int(window), int(depth), int(every)
         self._overlap = None                     # OverlappedEnergyAllReduce, created on the first forward (needs the device)
         self._energy_group = group
         self.max_pending = 64                    # reduced windows kept for reduced_energies() (exchange="window")
@@ -541,7 +578,10 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         device copy and an event); a helper thread issues the collective on a side stream, and the returned tensor waits for it
         when -- and only if -- its value is read.  ``e.backward()`` reads nothing.  Every rank must make the call, in the same
         order (it is a collective); calls under ``torch.no_grad()`` are collectives like any other and return the plain job-wide
-        value.  The values of the last ``depth`` calls stay readable.
+        value.  The values of the last ``depth`` calls stay readable.  ``every=n`` (constructor): one collective per ``n`` calls, issued
+        with the n-th -- for steps of a few tens of microseconds, where even an asynchronous collective per step is visible (8-way
+        strong scaling of the 512-sphere scene: 70 us per step, ~20 us of them the per-step exchange); a value is then readable from
+        the end of its window on, an earlier read raises (``flush_exchange()`` -- on every rank -- sends a partial window).
         ``exchange="step"``: the same all-reduce issued and waited for inside the call (stream-side); returns a plain tensor.
         ``exchange="window"`` (opt-in): returns THIS RANK's energy -- same gradient, which is all an optimiser needs --
         and files it into a :class:`WindowedEnergyAllReduce`: one asynchronous collective per ``window`` steps, nothing on
@@ -553,7 +593,7 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
         accumulate device tensors)."""
         if self.exchange == "overlap":
             if self._overlap is None:
-                self._overlap = OverlappedEnergyAllReduce(x_local.device, self._energy_group, self.depth)
+                self._overlap = OverlappedEnergyAllReduce(x_local.device, self._energy_group, self.depth, every=self.every)
             # Engine-free evaluation where nothing can tell the difference: a local evaluator that offers it (graph=True), a leaf
             # parameter without hooks.  The replay writes the energy into the exchange's ring slot itself.
             if (self.local is not None and torch.is_grad_enabled() and x_local.requires_grad and x_local.is_leaf
@@ -577,7 +617,7 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
             return _AddGlobal.apply(e_local, e_global)
         if self.exchange == "overlap":
             ticket = self._overlap.submit(e_local)
-            if not (torch.is_grad_enabled() and e_local.requires_grad):
+            if not (torch.is_grad_enabled() and e_local.requires_grad) and self.every == 1:
                 return self._overlap.value(ticket)
             return JobWideEnergy.wrap(e_local, self._overlap, ticket)
         if not torch.is_grad_enabled():
@@ -586,6 +626,11 @@ class ShardedSmoothnessBarrierEnergy(torch.nn.Module):
             self._reducer = WindowedEnergyAllReduce(self.window, e_local.device, self.group, max_pending=self.max_pending)
         self._reducer.push(e_local)
         return e_local
+
+    def flush_exchange(self) -> None:
+        """``exchange="overlap"`` with ``every`` > 1: issue the all-reduce of the current, partial window now.  A collective: every rank."""
+        if self._overlap is not None:
+            self._overlap.flush()
 
     def reduced_energies(self) -> torch.Tensor:
         """Job-wide energies of every step evaluated since the last call (1-D, evaluation order; flushes a partial window
