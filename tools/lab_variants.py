@@ -55,6 +55,10 @@ VARIANTS = {
             "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "fin_nodep": ("pricing: the finish kernel's staging rows at an address computed from the vertex number (2 or 3 rows from 2.5 k: results wrong) instead of "
+                  "from fin_off[k] -- what a class-major staging layout (rows at computable addresses, one dependent level less) could buy at most", [
+        (K, "        const int32_t e0 = FIN_LOAD(&a.fin_off[k]), e1 = FIN_LOAD(&a.fin_off[k + 1]);   // consecutive rows, tile order",
+            "        const int32_t e0 = int32_t((k * 5) >> 1), e1 = e0 + 2 + int32_t(k & 1);   // (pricing)")]),
     "ntfinish": ("the finish kernel's loads non-temporal (measured: finish kernel +50 %)", [(K, "#define FIN_LOAD(p) (*(p))", "#define FIN_LOAD(p) __builtin_nontemporal_load(p)")]),
     "tids": ("vertex ids, destinations and row table through ordinary (temporal) loads, as until round 6", [
         (K, "    const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)[size_t(tile) * size_t(a.vert_stride) + size_t(int(threadIdx.x) < a.vert_stride ? threadIdx.x : 0)]);",
