@@ -1,6 +1,6 @@
 /* Plain-C consumer of the DEVICE entry points of include/tssplat_amd.h: a compiled C99 program (no Python, no torch,
  * no ctypes) creates a handle on the GPU, evaluates energy + gradient through tsamd_forward_backward,
- * tsamd_forward, tsamd_backward, tsamd_evaluate_dev_coef and tsamd_graph_create / tsamd_graph_launch, and checks them against the float64 C oracle
+ * tsamd_forward, tsamd_backward, tsamd_evaluate_dev_coef and tsamd_graph_create / tsamd_graph_launch / tsamd_graph_launch_to, and checks them against the float64 C oracle
  * (oracle/c/tet_energy_oracle.c, test infrastructure) on a small lattice of tets.
  * Built and run by tests/test_gpu_parity.py::test_compiled_c_consumer_on_device:
  *   gcc -std=c99 abi_device.c -ltssplat_amd -ltet_energy_oracle -lamdhip64 */
@@ -100,7 +100,7 @@ int main(void)
         for (i = 0; i < 3 * NV; ++i) gn += g_ref[i] * g_ref[i];
         gn = sqrt(gn);
         if (E_ref[2] <= 0.0) return 13; /* the case is meant to exercise the inversion penalty */
-        for (variant = 0; variant < 4; ++variant) {
+        for (variant = 0; variant < 5; ++variant) {
             HIPCHK(hipMemset(d_g, 0xff, sizeof g_gpu));
             if (variant == 0)
                 rc = tsamd_forward_backward(h, d_x, d_go, c1, c2, order, NULL, d_e, d_g);
@@ -108,12 +108,34 @@ int main(void)
                 rc = tsamd_evaluate_dev_coef(h, d_x, d_go, d_coef, order, NULL, d_e, d_g);
             else if (variant == 2)
                 rc = tsamd_forward(h, d_x, c1, c2, order, NULL, d_e) || tsamd_backward(h, d_x, d_go, c1, c2, order, NULL, d_g);
-            else { /* the library-owned HIP graph: first launch with other coefficients, then with the real ones */
+            else if (variant == 3) { /* the library-owned HIP graph: first launch with other coefficients, then with the real ones */
                 tsamd_graph *gr = NULL;
                 rc = tsamd_graph_create(h, d_x, d_go, order, d_e, d_g, &gr) || tsamd_graph_launch(gr, 3.f * c1, 0.5f * c2, NULL) ||
                      tsamd_graph_launch(gr, c1, c2, NULL);
                 HIPCHK(hipDeviceSynchronize());
                 tsamd_graph_destroy(gr);
+            } else { /* the replay with its outputs redirected per launch: energy ALSO to a second address, gradient to another buffer */
+                tsamd_graph *gr = NULL;
+                float *d_e2 = NULL, *d_g2 = NULL, e_copy = -1.f, e_own = -2.f;
+                HIPCHK(hipMalloc((void **)&d_e2, sizeof(float)));
+                HIPCHK(hipMalloc((void **)&d_g2, sizeof g_gpu));
+                HIPCHK(hipMemset(d_g2, 0xff, sizeof g_gpu));
+                rc = tsamd_graph_create(h, d_x, d_go, order, d_e, d_g, &gr) || tsamd_graph_launch(gr, c1, c2, NULL) /* own buffers first */ ||
+                     tsamd_graph_launch_to(gr, c1, c2, NULL, d_e2, d_g2);
+                HIPCHK(hipDeviceSynchronize());
+                HIPCHK(hipMemcpy(&e_copy, d_e2, sizeof e_copy, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(&e_own, d_e, sizeof e_own, hipMemcpyDeviceToHost));
+                if (rc == TSAMD_OK && e_copy != e_own) return 18;              /* both destinations hold the same value */
+                HIPCHK(hipMemcpy(d_g, d_g2, sizeof g_gpu, hipMemcpyDeviceToDevice)); /* (checked below like every variant's gradient) */
+                /* a graph without a gradient cannot redirect one: loud */
+                if (rc == TSAMD_OK) {
+                    tsamd_graph *ge = NULL;
+                    if (tsamd_graph_create(h, d_x, NULL, order, d_e, NULL, &ge) != TSAMD_OK) return 19;
+                    if (tsamd_graph_launch_to(ge, c1, c2, NULL, NULL, d_g2) == TSAMD_OK) return 20;
+                    tsamd_graph_destroy(ge);
+                }
+                tsamd_graph_destroy(gr);
+                hipFree(d_e2), hipFree(d_g2);
             }
             if (rc != TSAMD_OK) {
                 fprintf(stderr, "evaluate (variant %d): %s\n", variant, tsamd_last_error());
