@@ -55,6 +55,14 @@ VARIANTS = {
             "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    "fold_price": ("pricing: NO finish launch; every workgroup ends with a device-scope release fence + one atomic on a counter (in the first dword of the "
+                   "energy partials' last pair: results wrong) -- the floor of a finish folded into the tile kernel for small plans (the last tile of a "
+                   "sphere to arrive sums its shared vertices, the last of all reduces the energy)", [
+        (K, "        if (64 * nw < td.n_verts) {   // more vertices than lanes (rare;", 
+            "        __threadfence();\n        __syncthreads();\n        if (tid == 0) atomicAdd(reinterpret_cast<unsigned int *>(a.partials + 2 * size_t(a.n_tiles)), 1u);\n        if (64 * nw < td.n_verts) {   // more vertices than lanes (rare;"),
+        (K, "    if (f.n_finish > 0) {\n        // one vertex per thread", "    if (f.n_finish < 0) {\n        // one vertex per thread"),
+        (K, "    } else if (f.energy) {\n        r.finish_fn = reinterpret_cast<const void *>(&energy_reduce_kernel);", "    } else if (f.energy && !e.grad) {\n        r.finish_fn = reinterpret_cast<const void *>(&energy_reduce_kernel);"),
+        ("capi.cpp", "upload(h->d_partials, nullptr, P.tiles.size() * 2, h->device_bytes)", "upload(h->d_partials, nullptr, P.tiles.size() * 2 + 2, h->device_bytes)")]),
     "fin_nodep": ("pricing: the finish kernel's staging rows at an address computed from the vertex number (2 or 3 rows from 2.5 k: results wrong) instead of "
                   "from fin_off[k] -- what a class-major staging layout (rows at computable addresses, one dependent level less) could buy at most", [
         (K, "        const int32_t e0 = FIN_LOAD(&a.fin_off[k]), e1 = FIN_LOAD(&a.fin_off[k + 1]);   // consecutive rows, tile order",
