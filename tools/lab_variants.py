@@ -63,6 +63,9 @@ VARIANTS = {
         (K, "    if (f.n_finish > 0) {\n        // one vertex per thread", "    if (f.n_finish < 0) {\n        // one vertex per thread"),
         (K, "    } else if (f.energy) {\n        r.finish_fn = reinterpret_cast<const void *>(&energy_reduce_kernel);", "    } else if (f.energy && !e.grad) {\n        r.finish_fn = reinterpret_cast<const void *>(&energy_reduce_kernel);"),
         ("capi.cpp", "upload(h->d_partials, nullptr, P.tiles.size() * 2, h->device_bytes)", "upload(h->d_partials, nullptr, P.tiles.size() * 2 + 2, h->device_bytes)")]),
+    "ntstore_excl": ("candidate: non-temporal stores for the EXCLUSIVE result rows (grad: not read again by this evaluation); staging rows stay temporal", [
+        (K, "                dst[0] = gx * sc;\n                dst[1] = gy * sc;\n                dst[2] = gz * sc;",
+            "                if (excl) {\n                    __builtin_nontemporal_store(gx * sc, dst);\n                    __builtin_nontemporal_store(gy * sc, dst + 1);\n                    __builtin_nontemporal_store(gz * sc, dst + 2);\n                } else {\n                    dst[0] = gx * sc;\n                    dst[1] = gy * sc;\n                    dst[2] = gz * sc;\n                }")]),
     "fin_nodep": ("pricing: the finish kernel's staging rows at an address computed from the vertex number (2 or 3 rows from 2.5 k: results wrong) instead of "
                   "from fin_off[k] -- what a class-major staging layout (rows at computable addresses, one dependent level less) could buy at most", [
         (K, "        const int32_t e0 = FIN_LOAD(&a.fin_off[k]), e1 = FIN_LOAD(&a.fin_off[k + 1]);   // consecutive rows, tile order",
