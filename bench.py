@@ -404,6 +404,10 @@ def _run_rank(args, stdout_fd: int) -> None:
         return e.detach()
 
     def step_graph(i):
+        if reducer is not None:                          # the replay writes its energy into the exchange's ring slot itself
+            e = graphed.step(it0 + i % 900, energy_copy=reducer.slot())[0]
+            reducer.commit()
+            return e
         return graphed.step(it0 + i % 900)[0]            # (coefficients refreshed on the device whenever they change: every step here)
 
     def step_graph_autograd(i):
@@ -420,7 +424,7 @@ def _run_rank(args, stdout_fd: int) -> None:
 
     def step(fn, i):
         e = fn(i)
-        if reducer is not None:             # the path's only exchange: the scalar energy (never on the gradient's path)
+        if reducer is not None and fn is not step_graph:   # the path's only exchange: the scalar energy (never on the gradient's path)
             reducer.push(e)
         return e
 

@@ -420,6 +420,18 @@ def test_overlapped_exchange_one_collective_per_window():
             assert all(abs(v - E) <= 3e-6 * abs(E) for v, E in zip(r["vals"], Es)), (rank, use_ext, r["vals"], Es)
 
 
+def test_windowed_reducer_slots_filled_by_the_evaluation():
+    """slot() / commit(): the evaluation writes its energy into the ring itself (a replay's second energy destination) -- same values and
+    window boundaries as push()."""
+    from tssplat_amd.sharding import WindowedEnergyAllReduce
+    a, b = WindowedEnergyAllReduce(4, "cpu"), WindowedEnergyAllReduce(4, "cpu")
+    for k in range(10):
+        a.push(torch.tensor(float(k) * 1.5))
+        b.slot().fill_(float(k) * 1.5)
+        b.commit()
+    assert torch.equal(a.results(), b.results()) and a.results().numel() == 0
+
+
 def test_rejects_spheres_that_share_vertices():
     rest, tets, vo, to, _ = _scene()
     bad = tets.copy()

@@ -111,13 +111,14 @@ class GraphedSmoothnessBarrier:
                                                None if grad_out is None else grad_out.data_ptr()))
         return self.energy, (self.grad if grad_out is None else grad_out)
 
-    def step(self, it: int, c1: float | None = None, c2: float | None = None):
+    def step(self, it: int, c1: float | None = None, c2: float | None = None, energy_copy: torch.Tensor | None = None):
         """One evaluation at iteration ``it``: coefficients from ``coeff_scheduler(it)`` unless given, order 4 after
-        ``FLAGS.increase_order_iter``.  Returns ``(energy, grad)`` -- the static device buffers."""
+        ``FLAGS.increase_order_iter``.  Returns ``(energy, grad)`` -- the static device buffers.  ``energy_copy``: see
+        :meth:`evaluate`."""
         if c1 is None or c2 is None:
             c1, c2 = self.module.coeff_scheduler(it)
         order = 4 if it > self.module.FLAGS.increase_order_iter else 2
-        return self.evaluate(c1, c2, order)
+        return self.evaluate(c1, c2, order, energy_copy)
 
 
 class GraphReplayFunc(torch.autograd.Function):
