@@ -143,9 +143,13 @@ class EnergyExchange {
             cv_done_.wait(lock, [&] { return issued_[size_t(s)] != 0; });
             TORCH_CHECK(error_.empty(), "the energy all-reduce failed in the helper thread: ", error_);
             w = works_[size_t(s)];
-            works_[size_t(s)].reset();
+            // every slot of a window shares one handle: one stream-side wait serves them all (a wait per SLOT put a wait packet on the
+            // training stream every step: +4.5 us per step at 64 x kuhn19, tools/module_breakdown.py)
+            const int64_t w0 = s - s % every_;
+            for (int64_t k = w0; k < w0 + every_; ++k)
+                if (works_[size_t(k)] == w) works_[size_t(k)].reset();
         }
-        if (w) {
+        if (w && !w->isCompleted()) {   // (a finished collective needs no wait packet on the calling stream: slot re-use, 256 tickets later)
             py::gil_scoped_release nogil;
             w->wait();   // RCCL: the current stream waits; gloo: the host does
         }

@@ -290,8 +290,12 @@ class OverlappedEnergyAllReduce:
             raise RuntimeError("the energy all-reduce failed in the helper thread") from self._error
         w = self._works[s]
         if w is not None:
-            w.wait()                                          # (RCCL: stream-side; gloo: the host waits)
-            self._works[s] = None
+            if not w.is_completed():                          # (a finished collective needs no wait on the calling stream)
+                w.wait()                                      # (RCCL: stream-side; gloo: the host waits)
+            w0 = s - s % self.every                           # (every slot of a window shares the handle: one wait serves them all)
+            for k in range(w0, w0 + self.every):
+                if self._works[k] is w:
+                    self._works[k] = None
 
     # ---- training thread ----
     def reserve(self) -> tuple[int, torch.Tensor]:
