@@ -8,7 +8,12 @@ per evaluation: the sum of the scalar energies (8 bytes over xGMI, latency bound
 asynchronously so it never sits on the gradient's critical path).  No gradient exchange.
 
 The reference itself has no distributed code; this is new host logic, covered
-by world_size-2 gloo tests on CPU (tests/test_sharding_gloo.py).
+by world_size-2 and -8 gloo tests on CPU (tests/test_sharding_gloo.py).
+
+Three forms of that exchange: ``WindowedEnergyAllReduce`` (one collective per window of steps, issued by the caller: bench.py's loop),
+``OverlappedEnergyAllReduce`` (issued by a helper thread -- csrc/torch_exchange.cpp when the in-tree extension is there --, per step or
+per window, values readable by ticket) and the plain per-call all-reduce; ``ShardedSmoothnessBarrierEnergy`` is the module a trainer
+holds, ``JobWideEnergy`` the tensor its ``forward`` returns.
 """
 from __future__ import annotations
 
@@ -194,8 +199,9 @@ class WindowedEnergyAllReduce:
 
 
 class OverlappedEnergyAllReduce:
-    """One all-reduce PER STEP that costs the step nothing: issued by a helper thread on a side stream, waited for only by
-    whoever reads its result.
+    """One all-reduce per step (or per ``every`` steps) that costs the training THREAD nothing: issued by a helper thread on a side
+    stream, waited for only by whoever reads its result.  (What a collective per step still costs is on the GPU's timeline: measured
+    +28 us per step at the 8-way share of the 512-sphere scene -- hence ``every``.)
 
     ``submit(local_energy)`` (the training thread) copies the scalar into a ring slot on the current stream, records an event
     and hands (slot, event) to the helper thread -- a few microseconds, no collective call.  The helper makes a side stream
