@@ -55,6 +55,126 @@ VARIANTS = {
             "    if (e_b == 12345.678f) g_partials[0] = e_b;\n    if (WITH_GRAD) return;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
         (K, "        r.tile_lds = size_t(e.lds_bytes);", "        r.tile_lds = size_t(100 * 1024);"),
         (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 100 * 1024;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
+    # ---- round 6: a tile FED BY LDS-DMA, built and measured.  One 1 024-thread workgroup per CU (160 KiB) runs TWO
+    #      consecutive tiles: waves 0-11 evaluate tile A as the product does (planes from HBM into registers) while waves 12-15 -- the loaders --
+    #      fetch tile B's vertex ids and positions and pull its eleven non-neighbour planes into an LDS ring behind tile A's map with
+    #      global_load_lds (16 B per lane, no VGPRs); tile B then runs with its planes and positions read from LDS.  Results are the
+    #      product's (same arithmetic).  t(pair) - t(tile A alone, `onewg`) = what a DMA-fed tile costs a lone 12-wave workgroup. ----
+    "dma2": ("built: two tiles per 1 024-thread workgroup, the second one fed by LDS-DMA loader waves (see the comment above)", [
+        (K, """template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD, int SPT>
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, int32_t gv0)
+{""", """constexpr uint32_t kRing = 81920u;                                // LDS ring of the DMA-fed tile: planes 0-1 and 4-12 of the device image ...
+constexpr uint32_t kRingPos = kRing + 11u * 1536u * 4u + 1024u;    // ... and its staged positions (float4 per vertex)
+template <bool WITH_GRAD, bool WEIGHTED, bool REBUILD, int SPT, int FEED = 0>
+__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, int32_t gv0)
+{"""),
+        (K, "    const int tid = threadIdx.x, nthr = blockDim.x;", "    const int tid = threadIdx.x, nthr = blockDim.x > 768 ? 768 : blockDim.x;   // (the loader waves are not the tile's)"),
+        (K, """    auto pair_u = [&](int q, VU &lo, VU &hi) {
+        if (kPaired) {""", """    auto pair_u = [&](int q, VU &lo, VU &hi) {
+        if (FEED == 1 && q == 0) {   // the vertex planes out of the ring
+            const v4u t = *lds_at<const v4u>(kRing + 16u * uint32_t(lt));
+            lo[0] = t.x, lo[1] = t.y, hi[0] = t.z, hi[1] = t.w;
+        } else if (kPaired) {"""),
+        (K, """    auto pair_f = [&](int q, VF &lo, VF &hi) {
+        if (kPaired) {""", """    auto pair_f = [&](int q, VF &lo, VF &hi) {
+        if (FEED == 1 && q < 12) {   // Dm^-1 out of the ring (planes 4 ... sit behind planes 0-1: two planes further down)
+            const v4f t = *lds_at<const v4f>(kRing + 4u * uint32_t(q - 2) * uint32_t(td.s_pad) + 16u * uint32_t(lt));
+            lo[0] = t.x, lo[1] = t.y, hi[0] = t.z, hi[1] = t.w;
+        } else if (kPaired) {"""),
+        (K, """        const size_t gv = size_t(gv0) * 3;
+        px = g_x[gv], py = g_x[gv + 1], pz = g_x[gv + 2];""", """        if (FEED == 1) {   // staged by the loader waves behind the ring
+            const v4f p4 = *lds_at<const v4f>(kRingPos + 16u * uint32_t(tid < td.n_verts ? tid : 0));
+            px = p4.x, py = p4.y, pz = p4.z;
+        } else {
+            const size_t gv = size_t(gv0) * 3;
+            px = g_x[gv], py = g_x[gv + 1], pz = g_x[gv + 2];
+        }"""),
+        (K, "        dm[8] = plane_f(12);", """        if (FEED == 1) {
+            const v2f t = *lds_at<const v2f>(kRing + 40u * uint32_t(td.s_pad) + 8u * uint32_t(lt));
+            dm[8][0] = t.x, dm[8][1] = t.y;
+        } else {
+            dm[8] = plane_f(12);
+        }"""),
+        (K, """struct FinishArgs {""", """// one wave-instruction of LDS-DMA: 64 lanes x 16 bytes from gsrc (per lane) to LDS bytes [lds_base, lds_base + 1024)
+__device__ __forceinline__ void dma16(const GLOBAL_AS unsigned char *gsrc, uint32_t lds_base)
+{
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void *)gsrc, (LDS_AS void *)(uintptr_t)lds_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(1024, 4) void tile_energy_dma2_kernel(const KernelArgs a)
+{
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_end = (xcd + 1) * a.tiles_per_xcd < a.n_tiles ? (xcd + 1) * a.tiles_per_xcd : a.n_tiles;
+    const int tile_a = xcd * a.tiles_per_xcd + 2 * jb, tile_b = tile_a + 1;
+    if (2 * jb >= a.tiles_per_xcd || tile_a >= tile_end) return;
+    const bool have_b = 2 * jb + 1 < a.tiles_per_xcd && tile_b < tile_end;
+    const int tid = threadIdx.x;
+    if (tid < 768) {   // ---- the twelve waves that evaluate: tile A from HBM, tile B from the ring ----
+        const int32_t gv0 = __builtin_nontemporal_load(&as_global(a.gvid)[size_t(tile_a) * size_t(a.vert_stride) + size_t(tid < a.vert_stride ? tid : 0)]);
+        __builtin_amdgcn_sched_barrier(0);
+        tile_body<true, false, false, 2, 0>(a, tile_a, gv0);
+        __syncthreads();   // tile A is done with its LDS; the loaders arrive here with tile B's planes landed
+        __syncthreads();   // (one barrier MORE between the loaders' wait and the first read of the ring: the guide's rule for two wave groups)
+        if (have_b) tile_body<true, false, false, 2, 1>(a, tile_b, 0);
+    } else {           // ---- the four loader waves ----
+        const int ll = tid - 768, lw = ll >> 6, lane = ll & 63;
+        if (have_b) {
+            const TileDesc tb = a.tiles[tile_b];
+            const auto g_gvid = as_global(a.gvid);
+            const auto g_x = as_global(a.x);
+            // ids -> positions of tile B's vertices (two per lane), staged behind the ring
+            const size_t vb = size_t(tile_b) * size_t(a.vert_stride);
+            const int v0 = ll, v1 = ll + 256;
+            const int32_t g0 = g_gvid[vb + size_t(v0 < a.vert_stride ? v0 : 0)], g1 = g_gvid[vb + size_t(v1 < a.vert_stride ? v1 : 0)];
+            const float p0x = g_x[size_t(g0) * 3], p0y = g_x[size_t(g0) * 3 + 1], p0z = g_x[size_t(g0) * 3 + 2];
+            const float p1x = g_x[size_t(g1) * 3], p1y = g_x[size_t(g1) * 3 + 1], p1z = g_x[size_t(g1) * 3 + 2];
+            if (v0 < tb.n_verts) *lds_at<v4f>(kRingPos + 16u * uint32_t(v0)) = v4f{p0x, p0y, p0z, 0.f};
+            if (v1 < tb.n_verts) *lds_at<v4f>(kRingPos + 16u * uint32_t(v1)) = v4f{p1x, p1y, p1z, 0.f};
+            // ... behind tile A's second barrier: its consumers have their own planes by then, the CU's ingest is free, and the DMA runs
+            // beside tile A's passes 2-3 / scatter / sums (issued at the head of tile A instead, it shares the ingest with tile A's
+            // own stream: 0.5975 ms against 0.5662 for one workgroup per CU without any DMA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+            // the planes: device-image bytes of planes 0-1 and of planes 4-12, 1 KiB per wave-instruction, no VGPRs
+            const GLOBAL_AS unsigned char *src = as_global(a.blob) + tb.blob_off;
+            const uint32_t b01 = 8u * uint32_t(tb.s_pad), b412 = 36u * uint32_t(tb.s_pad);
+            // (s_pad is a multiple of 4, not of 256: the last piece of a range is cut to the range by the lane mask -- a lane that
+            // is off writes nothing)
+            for (uint32_t k = uint32_t(lw); k * 1024u < b01; k += 4u) {
+                const uint32_t piece = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+                if (piece * 1024u + uint32_t(lane) * 16u < b01) dma16(src + size_t(piece) * 1024 + size_t(lane) * 16, kRing + piece * 1024u);
+            }
+            for (uint32_t k = uint32_t(lw); k * 1024u < b412; k += 4u) {
+                const uint32_t piece = uint32_t(__builtin_amdgcn_readfirstlane(int(k)));
+                if (piece * 1024u + uint32_t(lane) * 16u < b412)
+                    dma16(src + size_t(16u * uint32_t(tb.s_pad)) + size_t(piece) * 1024 + size_t(lane) * 16, kRing + b01 + piece * 1024u);
+            }
+        }
+        // tile A's six barriers (raw: a pending LDS-DMA must not be drained by them), the DMA landed before the seventh
+        for (int b = have_b ? 2 : 0; b < 6; ++b) __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (have_b)
+            for (int b = 0; b < 6; ++b) __builtin_amdgcn_s_barrier();
+    }
+}
+
+struct FinishArgs {"""),
+        (K, "        return grad ? TSAMD_FN(true, 768, 6, false, false, 2) : TSAMD_FN(false, 768, 6, false, false, 2);\n    }\n    if (weighted || rebuild) return nullptr;",
+            "        return grad ? reinterpret_cast<const void *>(&tile_energy_dma2_kernel) : TSAMD_FN(false, 768, 6, false, false, 2);\n    }\n    if (weighted || rebuild) return nullptr;"),
+        (K, """        r.tile_block = dim3(unsigned(e.block_threads));
+        r.tile_grid = dim3(unsigned(8 * k.tiles_per_xcd));
+        r.tile_lds = size_t(e.lds_bytes);""", """        r.tile_block = dim3(unsigned(e.block_threads));
+        r.tile_grid = dim3(unsigned(8 * k.tiles_per_xcd));
+        r.tile_lds = size_t(e.lds_bytes);
+        if (r.tile_fn == reinterpret_cast<const void *>(&tile_energy_dma2_kernel)) {
+            r.tile_block = dim3(1024u);
+            r.tile_grid = dim3(unsigned(8 * ((k.tiles_per_xcd + 1) / 2)));
+            r.tile_lds = size_t(163840);
+        }"""),
+        (K, "    if (lds_bytes <= configured[dev]) return hipSuccess;", "    lds_bytes = 163840;\n    if (lds_bytes <= configured[dev]) return hipSuccess;")]),
     "fold_price": ("pricing: NO finish launch; every workgroup ends with a device-scope release fence + one atomic on a counter (in the first dword of the "
                    "energy partials' last pair: results wrong) -- the floor of a finish folded into the tile kernel for small plans (the last tile of a "
                    "sphere to arrive sums its shared vertices, the last of all reduces the energy)", [
@@ -196,6 +316,23 @@ VARIANTS = {
         (K, "        if (wave & 4) {   // (a permutation", "        if (false) {   // (a permutation")]),
 }
 
+
+# debugging aids of `dma2`: one ingredient of the DMA-fed tile taken from HBM again
+_D = VARIANTS["dma2"][1]
+VARIANTS["dma2_chk"] = ("dma2 debug: tile B takes Dm^-1 from HBM, compares the ring with it and adds 1000 per mismatching lane-load to the barrier energy", _D + [
+    (K, """            const v4f t = *lds_at<const v4f>(kRing + 4u * uint32_t(q - 2) * uint32_t(td.s_pad) + 16u * uint32_t(lt));
+            lo[0] = t.x, lo[1] = t.y, hi[0] = t.z, hi[1] = t.w;""",
+        """            const v4f t = *lds_at<const v4f>(kRing + 4u * uint32_t(q - 2) * uint32_t(td.s_pad) + 16u * uint32_t(lt));
+            const VF2 h = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS VF2 *>(pl + q * td.s_pad + 2 * SPT * lt));
+            if (active && (t.x != h[0] || t.y != h[1] || t.z != h[2] || t.w != h[3])) dbg_mismatch += 1000.f;
+            lo[0] = h[0], lo[1] = h[1], hi[0] = h[2], hi[1] = h[3];"""),
+    (K, "    auto pair_u = [&](int q, VU &lo, VU &hi) {", "    float dbg_mismatch = 0.f;\n    auto pair_u = [&](int q, VU &lo, VU &hi) {"),
+    (K, "    float e_b = 0.f, e_s = 0.f;", "    float e_b = dbg_mismatch, e_s = 0.f;\n    if (FEED == 1 && tid == 0 && *lds_at<const uint32_t>(kRingPos - 16u) != uint32_t(tile)) e_b += 1.0e6f;"),
+    (K, """        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();""", """        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (ll == 0) *lds_at<uint32_t>(kRingPos - 16u) = uint32_t(tile_b);   // (debug: "everything of tile B has landed")
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();""")])
 
 COMBOS = {"fs": ["fma4", "sdwa"]}     # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
 

@@ -83,6 +83,26 @@ __global__ __launch_bounds__(768) void ingest_vgpr(const unsigned char *base, si
     if (acc == 123.456f) sink[0] = 1;
 }
 
+// ---- 0. where in a 160 KiB LDS can an LDS-DMA land?  (one wave copies 1 KiB of a known pattern to `base`, reads it back with ds_read) ----
+__global__ __launch_bounds__(64) void dma_where(const unsigned *src, unsigned base, unsigned *mismatches)
+{
+    extern __shared__ unsigned char smem[];
+    const int lane = threadIdx.x;
+    for (unsigned i = lane; i < 163840u / 4u; i += 64) ((LDS_AS unsigned *)(uintptr_t)0)[i] = 0xdeadbeefu;
+    __syncthreads();
+    dma16(reinterpret_cast<const unsigned char *>(src) + size_t(lane) * 16, base);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned bad = 0;
+    for (int j = 0; j < 4; ++j) bad += ((LDS_AS unsigned *)(uintptr_t)(base + 16u * unsigned(lane)))[j] != src[4 * lane + j];
+    // where did it go instead?  (first dword of the pattern)
+    unsigned found = 0xffffffffu;
+    for (unsigned i = lane; i < 163840u / 4u; i += 64)
+        if (((LDS_AS unsigned *)(uintptr_t)0)[i] == src[0] && 4u * i < found) found = 4u * i;
+    atomicAdd(mismatches, bad);
+    if (found != 0xffffffffu) atomicMin(mismatches + 1, found);
+}
+
 // ---- 2. loader / consumer workgroup ----
 // LDS map: records [0, 72 KB) (1 536 records of 48 B), ring [72 KB, 152 KB).
 constexpr unsigned kRecBytes = 1536u * 48u, kRingBytes = 80u * 1024u;
@@ -271,6 +291,23 @@ int main()
     }
     CHECK(hipMalloc(&g_tok, tok.size() * 4));
     CHECK(hipMemcpy(g_tok, tok.data(), tok.size() * 4, hipMemcpyHostToDevice));
+    {   // where can an LDS-DMA land?
+        std::vector<unsigned> pat(256);
+        for (int i = 0; i < 256; ++i) pat[i] = 0x51000000u + unsigned(i);
+        unsigned *d_pat, *d_mm;
+        CHECK(hipMalloc(&d_pat, 1024));
+        CHECK(hipMalloc(&d_mm, 8));
+        CHECK(hipMemcpy(d_pat, pat.data(), 1024, hipMemcpyHostToDevice));
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(dma_where), hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        for (unsigned base : {0u, 32768u, 65536u - 1024u, 65536u, 98304u, 131072u - 1024u, 131072u, 140000u & ~15u, 162816u}) {
+            unsigned init[2] = {0u, 0xffffffffu}, mm[2];
+            CHECK(hipMemcpy(d_mm, init, 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(dma_where, dim3(1), dim3(64), 163840, 0, d_pat, base, d_mm);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(mm, d_mm, 8, hipMemcpyDeviceToHost));
+            printf("LDS-DMA to LDS byte %6u: %3u of 256 dwords wrong; the pattern's first dword sits at LDS byte %u\n", base, mm[0], mm[1]);
+        }
+    }
     printf("clock64 ticks at the shader clock's constant reference (100 MHz class counters report fewer 'cycles' -- compare lines, and kernel ms)\n");
     auto kd = ingest_dma<7>;
     auto kv = ingest_vgpr<7>;
