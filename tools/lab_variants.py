@@ -334,7 +334,69 @@ VARIANTS["dma2_chk"] = ("dma2 debug: tile B takes Dm^-1 from HBM, compares the r
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();""")])
 
-COMBOS = {"fs": ["fma4", "sdwa"]}     # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
+# `dma2` leaves the head of the DMA-fed tile on HBM: the LDS is full (two tile maps' worth: records + ring), so the neighbour planes, the row
+# table and the descriptor of tile B are fetched when tile B starts -- with its planes already in LDS there is nothing left to hide them
+# behind.  `dma2p` has the CONSUMERS fetch them into registers (five VGPRs; the 1 024-thread workgroup has 128) a phase before tile A ends.
+VARIANTS["dma2p"] = ("dma2 + tile B's neighbour planes / row table / descriptor prefetched into the consumers' registers at tile A's scatter", _D + [
+    (K, "constexpr uint32_t kRing = 81920u; ", "struct NextHead {\n    TileDesc td;\n    uint32_t nb[4];\n    uint32_t row0;\n};\nconstexpr uint32_t kRing = 81920u; "),
+    (K, "__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, int32_t gv0)\n{",
+        "__device__ __forceinline__ void tile_body(const KernelArgs &a, const int tile, int32_t gv0, NextHead *nh = nullptr)\n{"),
+    (K, "    const TileDesc td = a.tiles[tile];", "    const TileDesc td = FEED == 1 ? nh->td : a.tiles[tile];"),
+    (K, "    pair_u(2, q_nb01, q_nb23);", """    if (FEED == 1) {
+        q_nb01[0] = nh->nb[0], q_nb01[1] = nh->nb[1], q_nb23[0] = nh->nb[2], q_nb23[1] = nh->nb[3];
+    } else {
+        pair_u(2, q_nb01, q_nb23);
+    }"""),
+    (K, "    if (WITH_GRAD) row0 = __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);",
+        "    if (WITH_GRAD) row0 = FEED == 1 ? nh->row0 : __builtin_nontemporal_load(&g_rowtab[tid < 65 ? tid : 64]);"),
+    (K, "        __syncthreads();   // all waves done with H and with the staged positions", """        if (FEED == 0 && nh) {   // the head of the NEXT tile, a phase ahead (behind dst_row: the in-order wait for that one leaves these in flight)
+            const GLOBAL_AS uint32_t *npl = reinterpret_cast<const GLOBAL_AS uint32_t *>(g_blob + nh->td.blob_off);
+            const int nlt = tid < nh->td.s_pad / SPT ? tid : 0;
+            const v4u t = __builtin_nontemporal_load(reinterpret_cast<const GLOBAL_AS v4u *>(npl + 2 * nh->td.s_pad + 4 * nlt));
+            nh->nb[0] = t.x, nh->nb[1] = t.y, nh->nb[2] = t.z, nh->nb[3] = t.w;
+            const GLOBAL_AS uint16_t *nrt = reinterpret_cast<const GLOBAL_AS uint16_t *>(npl + size_t(kPlanes) * nh->td.s_pad);
+            nh->row0 = __builtin_nontemporal_load(&nrt[tid < 65 ? tid : 64]);
+        }
+        __syncthreads();   // all waves done with H and with the staged positions"""),
+    (K, """        tile_body<true, false, false, 2, 0>(a, tile_a, gv0);""", """        NextHead nh;
+        nh.td = a.tiles[have_b ? tile_b : tile_a];   // (scalar loads: back with tile A's own descriptor)
+        tile_body<true, false, false, 2, 0>(a, tile_a, gv0, &nh);"""),
+    (K, "        if (have_b) tile_body<true, false, false, 2, 1>(a, tile_b, 0);", "        if (have_b) tile_body<true, false, false, 2, 1>(a, tile_b, 0, &nh);")])
+
+# where the time of a pair goes: 100 MHz timestamps (s_memrealtime) of wave 0 and of loader wave 12 of two mid-launch workgroups, printed
+_T = "__builtin_amdgcn_s_memrealtime()"
+VARIANTS["dma2p_t"] = ("dma2p + phase timestamps of two mid-launch workgroups (printf; run a handful of evaluations only)", VARIANTS["dma2p"][1] + [(_f, _o, _n.replace("@T@", _T)) for _f, _o, _n in [
+    (K, "    uint32_t row0;\n};\nconstexpr uint32_t kRing", "    uint32_t row0;\n    unsigned long long ts[3];\n};\nconstexpr uint32_t kRing"),
+    (K, "    __syncthreads();\n    // behind the barrier: what pass 2 and the end of the tile need",
+        "    __syncthreads();\n    if (nh) nh->ts[0] = @T@;\n    // behind the barrier: what pass 2 and the end of the tile need"),
+    (K, "    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----",
+        "    if (nh) nh->ts[1] = @T@;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
+    (K, "        if (FEED == 0 && nh) {   // the head of the NEXT tile", "        if (nh) nh->ts[2] = @T@;\n        if (FEED == 0 && nh) {   // the head of the NEXT tile"),
+    (K, "        NextHead nh;\n", "        NextHead nh;\n        const unsigned long long T0 = @T@;\n"),
+    (K, "        if (have_b) tile_body<true, false, false, 2, 1>(a, tile_b, 0, &nh);", """        const unsigned long long T2 = @T@;
+        NextHead nhb = nh;
+        if (have_b) tile_body<true, false, false, 2, 1>(a, tile_b, 0, &nhb);
+        const unsigned long long T3 = @T@;
+        if (tid == 0 && have_b && (blockIdx.x == 4000 || blockIdx.x == 4003 || blockIdx.x == 7001))
+            printf("cons blk %d (x10 ns)  A: positions %llu pass1 %llu scatter %llu end %llu | join %llu | B: positions %llu pass1 %llu scatter %llu end %llu\\n", int(blockIdx.x),
+                   nh.ts[0] - T0, nh.ts[1] - T0, nh.ts[2] - T0, T1 - T0, T2 - T1, nhb.ts[0] - T2, nhb.ts[1] - T2, nhb.ts[2] - T2, T3 - T2);"""),
+    (K, "        __syncthreads();   // tile A is done with its LDS; the loaders arrive here", "        const unsigned long long T1 = @T@;\n        __syncthreads();   // tile A is done with its LDS; the loaders arrive here"),
+    (K, "        const int ll = tid - 768, lw = ll >> 6, lane = ll & 63;", "        const int ll = tid - 768, lw = ll >> 6, lane = ll & 63;\n        const unsigned long long L0 = @T@;\n        unsigned long long L1 = L0, L2 = L0;"),
+    (K, "            // the planes: device-image bytes of planes 0-1 and of planes 4-12, 1 KiB per wave-instruction, no VGPRs", "            L1 = @T@;\n            // the planes: device-image bytes of planes 0-1 and of planes 4-12, 1 KiB per wave-instruction, no VGPRs"),
+    (K, "        // tile A's six barriers (raw: a pending LDS-DMA must not be drained by them), the DMA landed before the seventh", "        L2 = @T@;\n        // tile A's six barriers (raw: a pending LDS-DMA must not be drained by them), the DMA landed before the seventh"),
+    (K, """        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (have_b)""", """        const unsigned long long L3 = @T@;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long L4 = @T@;
+        if (ll == 0 && have_b && (blockIdx.x == 4000 || blockIdx.x == 4003 || blockIdx.x == 7001))
+            printf("load blk %d (x10 ns)  dma issue starts %llu, issued %llu, tile A's barriers passed %llu, landed %llu\\n", int(blockIdx.x), L1 - L0, L2 - L0, L3 - L0, L4 - L0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+        if (have_b)""")]])
+
+COMBOS = {"fs": ["fma4", "sdwa"]}    # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
 
 
 FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> function(list of device flags) -> list
