@@ -396,7 +396,91 @@ VARIANTS["dma2p_t"] = ("dma2p + phase timestamps of two mid-launch workgroups (p
         __builtin_amdgcn_s_barrier();
         if (have_b)""")]])
 
-COMBOS = {"fs": ["fma4", "sdwa"]}    # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
+# the product kernel's phases as seen by wave 0 of a few mid-launch workgroups (two workgroups per CU: each one's phases stretch by what the other takes)
+_BLK = "(blockIdx.x == 4000 || blockIdx.x == 4003 || blockIdx.x == 7001 || blockIdx.x == 9002 || blockIdx.x == 12005 || blockIdx.x == 15000)"
+VARIANTS["stamps"] = ("product kernel + 100 MHz phase timestamps of wave 0 in six mid-launch workgroups (printf; run a handful of evaluations only)", [(_f, _o, _n.replace("@T@", _T).replace("@BLK@", _BLK)) for _f, _o, _n in [
+    (K, "    const TileDesc td = a.tiles[tile];", "    unsigned long long ts[8];\n    ts[0] = @T@;\n    const TileDesc td = a.tiles[tile];"),
+    (K, "    __syncthreads();\n    // behind the barrier: what pass 2 and the end of the tile need", "    __syncthreads();\n    ts[1] = @T@;\n    // behind the barrier: what pass 2 and the end of the tile need"),
+    (K, "    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----", "    ts[2] = @T@;\n    // ---- pass 2: H = L F on owned slots (0 on halo slots), E_s = 1/2 |H|^2 ----"),
+    (K, "    __syncthreads();  // every read of F is done; overwrite it with H in place", "    __syncthreads();  // every read of F is done; overwrite it with H in place\n    ts[3] = @T@;"),
+    (K, "        publish_wave_sums();\n        __syncthreads();\n        sum_waves();\n", "        publish_wave_sums();\n        __syncthreads();\n        ts[4] = @T@;\n        sum_waves();\n"),
+    (K, "        __syncthreads();   // all waves done with H and with the staged positions", "        __syncthreads();   // all waves done with H and with the staged positions\n        ts[5] = @T@;"),
+    (K, "        __syncthreads();\n\n        // ---- per-vertex sums: lane = vertex", "        __syncthreads();\n        ts[6] = @T@;\n\n        // ---- per-vertex sums: lane = vertex"),
+    (K, "    }\n#undef t_own\n}", """        ts[7] = @T@;
+        if ((tid == 0 || tid == 704) && @BLK@)
+            printf("blk %d wave %d (x10 ns): positions %llu pass1 %llu pass2 %llu H-stored %llu pass3 %llu scatter %llu sums+stores %llu | total %llu\\n", int(blockIdx.x), tid >> 6,
+                   ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6], ts[7] - ts[0]);
+    }
+#undef t_own
+}""")]])
+
+# ... and the inside of the per-vertex sums (wave 0 = the block of the fullest vertices): row loop / wait for the destination ids / stores issued
+VARIANTS["stamps2"] = ("stamps + the per-vertex sums split into row loop, wait for vdst, stores", [(_f, _o, _n.replace("@T@", _T).replace("@BLK@", _BLK)) for _f, _o, _n in [
+    (K, "    const TileDesc td = a.tiles[tile];", "    unsigned long long ts[4];\n    int sum_rows = 0;\n    const TileDesc td = a.tiles[tile];"),
+    (K, "        __syncthreads();\n\n        // ---- per-vertex sums: lane = vertex", "        __syncthreads();\n        ts[0] = @T@;\n\n        // ---- per-vertex sums: lane = vertex"),
+    (K, "            if (v < td.n_verts) {\n                const bool excl = row >= 0;", "            sum_rows = rows;\n            asm volatile(\"\" : \"+v\"(gx), \"+v\"(gy), \"+v\"(gz));\n            ts[1] = @T@;\n            asm volatile(\"\" : \"+v\"(row));\n            asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n            ts[2] = @T@;\n            if (v < td.n_verts) {\n                const bool excl = row >= 0;"),
+    (K, "    }\n#undef t_own\n}", """        ts[3] = @T@;
+        if ((tid == 0 || tid == 64 || tid == 192) && @BLK@)
+            printf("blk %d wave %d (x10 ns): rows %d: row loop %llu, wait for vdst %llu, stores issued %llu\\n", int(blockIdx.x), tid >> 6, sum_rows, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]);
+    }
+#undef t_own
+}""")]])
+
+# candidate (round 6, from the stamps): the row loop of the per-vertex sums is one wave's dependent chain -- ~45 instructions per four rows, then a
+# wait for eight LDS reads: 0.17 us per trip, 2.3 us for a.veg's 56-row hubs (wave 0 is the last wave of its workgroup by that much).  Two trips in
+# flight: the reads of trip k + 1 are issued before trip k is added up (same order of additions: bit-identical results).
+VARIANTS["sums_pipe"] = ("candidate: per-vertex sums software-pipelined, two trips of four rows in flight", [
+    (K, """            for (int r = 0; r < rows; r += 4) {
+                const LDS_AS float *f[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
+                    f[u] = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gx += f[u][0];
+                    gy += f[u][1];
+                    gz += f[u][2];
+                }
+            }""", """            float A[4][3], B[4][3];
+            auto fetch = [&](int r, float (&d)[4][3]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t base = uint32_t(__builtin_amdgcn_readlane(int(tab), r + u)), w = uint32_t(__builtin_amdgcn_readlane(int(wid), r + u));
+                    const LDS_AS float *f = lds_at<const float>(v12 < w ? base + v12 : kZeroEntry);
+                    d[u][0] = f[0], d[u][1] = f[1], d[u][2] = f[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto add = [&](const float (&d)[4][3]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    gx += d[u][0];
+                    gy += d[u][1];
+                    gz += d[u][2];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (rows > 0) {
+                fetch(0, A);
+                int r = 4;
+                for (; r + 4 < rows; r += 8) {   // trips r / 4 and r / 4 + 1 both exist
+                    fetch(r, B);
+                    add(A);
+                    fetch(r + 4, A);
+                    add(B);
+                }
+                if (r < rows) {
+                    fetch(r, B);
+                    add(A);
+                    add(B);
+                } else {
+                    add(A);
+                }
+            }""")])
+
+COMBOS = {"fs": ["fma4", "sdwa"], "stamps_rows8": ["stamps", "rows8"]}    # ("undef" -- inactive lanes' arrays left undefined -- was adopted by the product kernel)
 
 
 FLAG_VARIANTS = {   # compiler-flag builds of the unpatched source: name -> function(list of device flags) -> list
@@ -411,6 +495,7 @@ DEFINE_VARIANTS = {
 }
 for _n, (_d, _f) in DEFINE_VARIANTS.items():
     VARIANTS[_n] = (_d, [])
+VARIANTS["stamps_rows8"] = ("stamps on top of rows8: does halving the longest walk shorten the workgroup, and what do the other phases do?", [])
 for _n in FLAG_VARIANTS:
     VARIANTS[_n] = (f"compiler flags: {_n}", [(K, "// gfx950 (MI355X / CDNA4) kernels", "// gfx950 (MI355X / CDNA4) kernels")])
 
